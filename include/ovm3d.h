@@ -1,0 +1,175 @@
+/*
+ * libovm3d - C ABI of the MI355X-native OVMono3D-LIFT inference path.
+ *
+ * The reference (nightgoodl/ovmono3d) is pure Python and has no FFI; the entry points below are the
+ * native equivalents of the Python plugin surface it exposes for this path. Each one cites the
+ * reference interface it replaces. All pointers are plain pointers, all sizes plain integers; no
+ * torch / C++ types cross the boundary. Device pointers are HIP device memory of the device the
+ * handle was created on. Functions return 0 on success and a negative OVM_ERR_* code otherwise and
+ * never throw; ovm_last_error() returns a message for the last failure on a handle.
+ *
+ * Threading: a handle is not thread-safe; use one handle per (device, stream). All work is
+ * stream-ordered on the caller's stream; functions do not synchronise unless documented.
+ * Ownership: the caller owns every input/output buffer; the handle owns packed weights + workspace
+ * (sized at create for max_batch / max_rois) and allocates nothing on the hot path.
+ */
+#ifndef OVM3D_H
+#define OVM3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OVM_OK 0
+#define OVM_ERR_INVALID (-1)
+#define OVM_ERR_HIP (-2)
+#define OVM_ERR_MISSING_WEIGHT (-3)
+#define OVM_ERR_SHAPE (-4)
+#define OVM_ERR_CAPACITY (-5)
+
+#define OVM_REC_FLOATS 48 /* detection record width, see OvmDet3D */
+
+typedef struct OvmHandle OvmHandle;
+typedef void* ovm_stream_t; /* hipStream_t */
+
+/* Model / path configuration: the inference-relevant keys of the reference config tree
+ * (cubercnn/config/config.py:80-92,118-239; configs/Base.yaml; configs/OVMono3D_dinov2_SFP.yaml). */
+typedef struct OvmConfig {
+  /* MODEL.DINO.MODEL_NAME table, reference cubercnn/modeling/backbone/dino.py:17-24 */
+  int32_t embed_dim, depth, heads;
+  int32_t pos_grid;         /* sqrt(#pretrained position embeddings) (37 for the 518px hub models) */
+  int32_t canvas;           /* MODEL.FPN.SQUARE_PAD (OVMono3D_dinov2_SFP.yaml:37), multiple of 14 */
+  int32_t fpn_channels;     /* MODEL.FPN.OUT_CHANNELS */
+  int32_t use_depth_fusion; /* MODEL.DINO.USE_DEPTH_FUSION (config.py:92) */
+  float pixel_mean[3];      /* MODEL.PIXEL_MEAN in tensor channel order */
+  float pixel_std[3];
+  /* ROI heads */
+  int32_t num_classes;      /* MODEL.ROI_HEADS.NUM_CLASSES */
+  int32_t fc_dim;           /* ROI_BOX_HEAD.FC_DIM / ROI_CUBE_HEAD.FC_DIM */
+  int32_t pooler_res;       /* 7 */
+  int32_t pooler_min_level, pooler_max_level; /* ROIPooler level clamp */
+  float virtual_focal;      /* ROI_CUBE_HEAD.VIRTUAL_FOCAL */
+  /* RPN + box head (reference configs/Base.yaml:45-66) */
+  float anchor_sizes[3];
+  float anchor_ratios[3];
+  int32_t rpn_pre_topk, rpn_post_topk;
+  float rpn_nms_thresh;
+  float score_thresh, nms_thresh;
+  int32_t detections_per_image;
+  /* build-specific */
+  int32_t precision;        /* 1 = fp16 operands, one MFMA pass; 3 = split fp16 (hi+lo), three passes */
+  int32_t max_batch, max_rois;
+} OvmConfig;
+
+/* One host-resident fp32 tensor of a checkpoint, named with the reference state_dict key
+ * (module tree printed at reference nohup.out:563-684; loaded at reference demo/demo.py:148). */
+typedef struct OvmTensor {
+  const char* name;
+  const float* data;
+  int32_t ndim;
+  int64_t shape[4];
+} OvmTensor;
+
+/* One input image: the per-image dict of the reference (demo/demo.py:82-85, dataset_mapper.py:72):
+ * 'image' uint8 at network resolution (any C/H/W element strides: CHW dict tensors and native NHWC both
+ * work without a copy), 'height'/'width' (original), 'K'. */
+typedef struct OvmImage {
+  const uint8_t* data;      /* device pointer */
+  int32_t height, width;    /* network resolution */
+  int64_t stride_c, stride_h, stride_w;
+  int32_t orig_height, orig_width;
+  float K[9];
+} OvmImage;
+
+/* Detection record, 48 x 4 bytes (fields of detectron2 Instances as filled at reference
+ * cubercnn/modeling/roi_heads/roi_heads.py:823-843 and consumed at omni3d_evaluation.py:1219-1249). */
+typedef struct OvmDet3D {
+  float box[4];        /* pred_boxes xyxy, original resolution (after detector_postprocess) */
+  float score;         /* sqrt(score2d * exp(-uncertainty)) */
+  int32_t category;    /* pred_classes */
+  float bbox3D[24];    /* 8 corners x (x,y,z), camera space */
+  float center_cam[3];
+  float center_2D[2];  /* original-resolution pixels */
+  float dimensions[3]; /* W, H, L */
+  float pose[9];       /* row-major 3x3, egocentric */
+  int32_t image;       /* index into the call's image array */
+} OvmDet3D;
+
+/* --- lifecycle ---------------------------------------------------------------------------------
+ * Replaces build_model(cfg) + DetectionCheckpointer.resume_or_load (reference rcnn3d.py:252-276,
+ * demo/demo.py:144-150): packs the named fp32 tensors into device-resident fp16(-split) GEMM layouts. */
+int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights, int32_t device, OvmHandle** out);
+int ovm_destroy(OvmHandle* h);
+const char* ovm_last_error(const OvmHandle* h);
+const char* ovm_version(void);
+
+/* --- backbone: build_dino_backbone(...).forward(x, prompt_depth) -> {p2,p3,p4}
+ * (reference dino.py:70-120,123-153,208-224; preprocess_image folded in, rcnn3d.py:88).
+ * images: host array of B descriptors. prompt_depth: device fp32 [B][1][depth_h][depth_w] or NULL.
+ * p2/p3/p4: device fp32 NHWC outputs [B][S/7][S/7][C], [B][S/14]..., [B][S/28]... or NULL to keep
+ * the features only inside the handle (ovm_cube_forward / ovm_rpn_box_forward read them there). */
+int ovm_backbone_forward(OvmHandle* h, const OvmImage* images, int32_t B, const float* prompt_depth,
+                         int32_t depth_h, int32_t depth_w, float* p2, float* p3, float* p4, ovm_stream_t stream);
+
+/* --- ROIHeads3D._forward_cube, eval branch (reference roi_heads.py:329-549,798-848) followed by
+ * GeneralizedRCNN._postprocess (rcnn3d.py:115). Uses the features of the last ovm_backbone_forward.
+ * boxes [n][4] xyxy at network resolution, scores [n], classes [n] int32, image_idx [n] int32 (sorted by
+ * image), all device. out: device [n] records; out_counts: device int32 [B] kept detections per image
+ * (records of empty post-processed boxes are dropped, order preserved). postprocess = 0 keeps every record
+ * with its network-resolution box (RCNN3D.inference(do_postprocess=False), rcnn3d.py:113-117). */
+int ovm_cube_forward(OvmHandle* h, const OvmImage* images, int32_t B, const float* boxes, const float* scores,
+                     const int32_t* classes, const int32_t* image_idx, int32_t n, int32_t postprocess, OvmDet3D* out,
+                     int32_t* out_counts, ovm_stream_t stream);
+
+/* --- RPN inference + ROIHeads3D._forward_box + FastRCNNOutputs.inference
+ * (reference rcnn3d.py:106, rpn.py:19-39 -> detectron2 RPN; roi_heads.py:252-296; fast_rcnn.py:57-143).
+ * Outputs up to detections_per_image rows per image, image-major: boxes [B*topk][4] network res,
+ * scores, classes, image_idx, and scores_full [B*topk][num_classes] (may be NULL); out_counts int32 [B]. */
+int ovm_rpn_box_forward(OvmHandle* h, const OvmImage* images, int32_t B, float* boxes, float* scores,
+                        int32_t* classes, int32_t* image_idx, float* scores_full, int32_t* out_counts,
+                        ovm_stream_t stream);
+
+/* --- detection gather over RCCL: replaces comm.gather(inference_json, dst=0)
+ * (reference omni3d_evaluation.py:717-720). comm is an ncclComm_t. counts_all (host, world ints) is
+ * filled on every rank; recv (device) must hold sum(counts_all) records on rank 0. */
+int ovm_gather_records(void* comm, int32_t rank, int32_t world, const OvmDet3D* send, int32_t n_send,
+                       OvmDet3D* recv, int32_t* counts_all, ovm_stream_t stream);
+
+/* --- host-side helpers (no GPU needed) -------------------------------------------------------- */
+/* dinov2 interpolate_pos_encoding (hub: offset 0.1, bicubic, no antialias): pos [1+M*M][D] -> out [1+G*G][D] */
+int ovm_host_interp_pos_embed(const float* pos, int32_t M, int32_t D, int32_t G, float* out);
+/* InferenceSampler contiguous shard [begin,end) of rank (reference cubercnn/data/build.py:320) */
+int ovm_host_shard_range(int64_t n_items, int32_t rank, int32_t world, int64_t* begin, int64_t* end);
+
+/* --- kernel-level entry points (parity tests and micro-benchmarks call the same kernels the model
+ * path launches). All pointers device; "split" fp16 tensors are a hi array and an optional lo array
+ * (x ~= hi + lo * 2^-11). */
+int ovm_op_split_f16(const float* x, int64_t n, uint16_t* hi, uint16_t* lo, ovm_stream_t stream);
+int ovm_op_gemm(const uint16_t* a_hi, const uint16_t* a_lo, int32_t lda, const uint16_t* w_hi, const uint16_t* w_lo,
+                int32_t M, int32_t N, int32_t K, const float* bias, int32_t relu, float* c, int32_t ldc,
+                int32_t precision, ovm_stream_t stream);
+int ovm_op_layernorm(const float* x, int32_t M, int32_t D, const float* gamma, const float* beta, float eps,
+                     float* y, ovm_stream_t stream);
+int ovm_op_attention(const float* qkv, int32_t B, int32_t T, int32_t heads, float* out, int32_t precision,
+                     ovm_stream_t stream);
+int ovm_op_roi_align(const float* p2, const float* p3, const float* p4, const int32_t* hw /* [3][2] */,
+                     const float* scales /* [3] */, int32_t C, int32_t out_res, int32_t min_level, int32_t max_level,
+                     const float* boxes, const int32_t* image_idx, int32_t n, float* out /* [n][res*res*C] (ph,pw,c) */,
+                     ovm_stream_t stream);
+int ovm_op_cube_decode(const float* head13, int32_t ld, const float* boxes, const float* scores, const int32_t* classes,
+                       const int32_t* image_idx, const OvmImage* images, int32_t B, int32_t n, float virtual_focal,
+                       int32_t postprocess, OvmDet3D* rec, int32_t* keep, ovm_stream_t stream);
+int ovm_op_nms(const float* boxes, const float* scores, int32_t n, float thresh, int32_t* keep_idx, int32_t* n_keep,
+               ovm_stream_t stream);
+
+/* --- introspection for tests: copy a named intermediate of the last forward into dst (device).
+ * names: "tokens" [B*T][D] fp32, "p2" / "p3" / "p4". Returns the element count or a negative error. */
+int64_t ovm_debug_copy(OvmHandle* h, const char* name, float* dst, int64_t capacity, ovm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OVM3D_H */

@@ -1,0 +1,262 @@
+"""Self-contained config node for the OVMono3D-LIFT inference path.
+
+Mirrors the key tree the reference builds with detectron2's yacs ``CfgNode``:
+``get_cfg()`` + ``get_cfg_defaults(cfg)`` (reference cubercnn/config/config.py:4-241),
+YAML files with ``_BASE_`` inheritance (reference configs/OVMono3D_dinov2_SFP.yaml:1)
+and trailing ``KEY VALUE`` overrides (reference demo/demo.py:137-139).
+
+Only keys read on the inference path carry defaults here; unknown keys found in a
+YAML file are accepted and stored (training keys are tolerated, never interpreted).
+Detectron2 is not a dependency.
+"""
+from __future__ import annotations
+
+import ast
+import copy
+import os
+from typing import Any, Iterable
+
+import yaml
+
+
+class CfgNode(dict):
+    """Attribute-style nested dict (the subset of yacs.CfgNode semantics the path uses)."""
+
+    def __init__(self, init: dict | None = None):
+        super().__init__()
+        object.__setattr__(self, "_frozen", False)
+        for k, v in (init or {}).items():
+            self[k] = CfgNode(v) if isinstance(v, dict) and not isinstance(v, CfgNode) else v
+
+    def __getattr__(self, name: str) -> Any:
+        try:
+            return self[name]
+        except KeyError as e:
+            raise AttributeError(name) from e
+
+    def __setattr__(self, name: str, value: Any) -> None:
+        if object.__getattribute__(self, "_frozen"):
+            raise AttributeError(f"Attempted to set {name} on a frozen CfgNode")
+        self[name] = value
+
+    def freeze(self) -> None:
+        object.__setattr__(self, "_frozen", True)
+        for v in self.values():
+            if isinstance(v, CfgNode):
+                v.freeze()
+
+    def defrost(self) -> None:
+        object.__setattr__(self, "_frozen", False)
+        for v in self.values():
+            if isinstance(v, CfgNode):
+                v.defrost()
+
+    def is_frozen(self) -> bool:
+        return object.__getattribute__(self, "_frozen")
+
+    def clone(self) -> "CfgNode":
+        return copy.deepcopy(self)
+
+    def __deepcopy__(self, memo):
+        out = CfgNode()
+        for k, v in self.items():
+            dict.__setitem__(out, k, copy.deepcopy(v, memo))
+        return out
+
+    # -- merging ---------------------------------------------------------------------------
+    def _merge_dict(self, other: dict) -> None:
+        for k, v in other.items():
+            if isinstance(v, dict):
+                if k not in self or not isinstance(self[k], CfgNode):
+                    self[k] = CfgNode()
+                self[k]._merge_dict(v)
+            else:
+                self[k] = _coerce(v, self.get(k))
+
+    def merge_from_file(self, path: str) -> None:
+        """YAML merge honouring ``_BASE_`` (resolved relative to the including file)."""
+        self._merge_dict(_load_yaml_with_base(path))
+
+    def merge_from_list(self, opts: Iterable[Any] | None) -> None:
+        opts = list(opts or [])
+        if len(opts) % 2 != 0:
+            raise ValueError(f"Override list has odd length: {opts}")
+        for full_key, raw in zip(opts[0::2], opts[1::2]):
+            node = self
+            parts = full_key.split(".")
+            for p in parts[:-1]:
+                if p not in node:
+                    raise KeyError(f"Non-existent config key: {full_key}")
+                node = node[p]
+            if parts[-1] not in node:
+                raise KeyError(f"Non-existent config key: {full_key}")
+            node[parts[-1]] = _coerce(_decode(raw), node[parts[-1]])
+
+    def dump(self) -> str:
+        return yaml.safe_dump(_to_plain(self), sort_keys=True)
+
+
+def _to_plain(node):
+    if isinstance(node, dict):
+        return {k: _to_plain(v) for k, v in node.items()}
+    if isinstance(node, tuple):
+        return [_to_plain(v) for v in node]
+    return node
+
+
+def _decode(raw):
+    if not isinstance(raw, str):
+        return raw
+    try:
+        return ast.literal_eval(raw)
+    except (ValueError, SyntaxError):
+        return raw
+
+
+def _coerce(value, old):
+    """yacs-style light type coercion: tuple<->list, int->float, '(1, 2)' strings."""
+    if isinstance(value, str) and isinstance(old, (tuple, list)):
+        value = _decode(value)
+    if isinstance(old, tuple) and isinstance(value, list):
+        return tuple(value)
+    if isinstance(old, list) and isinstance(value, tuple):
+        return list(value)
+    if isinstance(old, float) and isinstance(value, int) and not isinstance(value, bool):
+        return float(value)
+    if isinstance(value, str) and len(value) > 1 and value[0] == "(" and value[-1] == ")":
+        dec = _decode(value)
+        return dec
+    return value
+
+
+def _load_yaml_with_base(path: str) -> dict:
+    with open(path, "r") as f:
+        cfg = yaml.safe_load(f) or {}
+    base = cfg.pop("_BASE_", None)
+    if base is None:
+        return cfg
+    if not os.path.isabs(base):
+        base = os.path.join(os.path.dirname(path), base)
+    merged = _load_yaml_with_base(base)
+    _deep_update(merged, cfg)
+    return merged
+
+
+def _deep_update(dst: dict, src: dict) -> None:
+    for k, v in src.items():
+        if isinstance(v, dict) and isinstance(dst.get(k), dict):
+            _deep_update(dst[k], v)
+        else:
+            dst[k] = v
+
+
+def get_cfg() -> CfgNode:
+    """Detectron2-default subset for the keys this path reads (values = detectron2 0.6 defaults;
+    the effective values for the DINOv2 config are in reference nohup.out:92-557)."""
+    C = CfgNode()
+    C.VERSION = 2
+    C.OUTPUT_DIR = "./output"
+    C.SEED = -1
+    C.VIS_PERIOD = 0
+    C.INPUT = CfgNode(dict(MIN_SIZE_TEST=800, MAX_SIZE_TEST=1333, FORMAT="BGR",
+                           MIN_SIZE_TRAIN=(800,), MAX_SIZE_TRAIN=1333))
+    C.DATASETS = CfgNode(dict(TRAIN=(), TEST=()))
+    C.DATALOADER = CfgNode(dict(NUM_WORKERS=4))
+    C.TEST = CfgNode(dict(DETECTIONS_PER_IMAGE=100, EVAL_PERIOD=0))
+    C.SOLVER = CfgNode(dict(IMS_PER_BATCH=16))
+    M = CfgNode()
+    M.DEVICE = "cuda"
+    M.META_ARCHITECTURE = "GeneralizedRCNN"
+    M.WEIGHTS = ""
+    M.MASK_ON = False
+    M.PIXEL_MEAN = [103.530, 116.280, 123.675]
+    M.PIXEL_STD = [1.0, 1.0, 1.0]
+    M.BACKBONE = CfgNode(dict(NAME="build_resnet_backbone", FREEZE_AT=2))
+    M.FPN = CfgNode(dict(IN_FEATURES=[], OUT_CHANNELS=256, NORM="", FUSE_TYPE="sum"))
+    M.PROPOSAL_GENERATOR = CfgNode(dict(NAME="RPN", MIN_SIZE=0))
+    M.ANCHOR_GENERATOR = CfgNode(dict(NAME="DefaultAnchorGenerator", SIZES=[[32, 64, 128, 256, 512]],
+                                      ASPECT_RATIOS=[[0.5, 1.0, 2.0]], OFFSET=0.0))
+    M.RPN = CfgNode(dict(HEAD_NAME="StandardRPNHead", IN_FEATURES=["res4"], BOUNDARY_THRESH=-1,
+                         BBOX_REG_WEIGHTS=(1.0, 1.0, 1.0, 1.0), PRE_NMS_TOPK_TEST=1000,
+                         POST_NMS_TOPK_TEST=1000, PRE_NMS_TOPK_TRAIN=12000, POST_NMS_TOPK_TRAIN=2000,
+                         NMS_THRESH=0.7, CONV_DIMS=[-1]))
+    M.ROI_HEADS = CfgNode(dict(NAME="Res5ROIHeads", NUM_CLASSES=80, IN_FEATURES=["res4"],
+                               SCORE_THRESH_TEST=0.05, NMS_THRESH_TEST=0.5, BATCH_SIZE_PER_IMAGE=512))
+    M.ROI_BOX_HEAD = CfgNode(dict(NAME="", BBOX_REG_WEIGHTS=(10.0, 10.0, 5.0, 5.0), POOLER_RESOLUTION=14,
+                                  POOLER_SAMPLING_RATIO=0, POOLER_TYPE="ROIAlignV2", NUM_FC=0, FC_DIM=1024,
+                                  NUM_CONV=0, CONV_DIM=256, NORM="", CLS_AGNOSTIC_BBOX_REG=False))
+    M.RESNETS = CfgNode(dict(DEPTH=50))
+    C.MODEL = M
+    return C
+
+
+def get_cfg_defaults(cfg: CfgNode) -> CfgNode:
+    """Adds the Cube R-CNN / OVMono3D keys (reference cubercnn/config/config.py:4-241).
+    Inference-relevant defaults only; cluster-specific absolute paths of the fork (:71,:76) are dropped."""
+    cfg.DATASETS.CATEGORY_NAMES = []
+    cfg.DATASETS.IGNORE_NAMES = []
+    cfg.DATASETS.TEST_BASE = ("Objectron_test",)
+    cfg.DATASETS.TEST_NOVEL = ()
+    cfg.DATASETS.CATEGORY_NAMES_BASE = ("bicycle", "books", "bottle", "camera", "cereal box",
+                                        "chair", "cup", "laptop", "shoes")
+    cfg.DATASETS.CATEGORY_NAMES_NOVEL = ()
+    cfg.DATASETS.ORACLE2D_FILES = CfgNode(dict(EVAL_MODE="target_aware"))
+
+    cfg.MODEL.FPN.IN_FEATURE = None
+    cfg.MODEL.FPN.SQUARE_PAD = 0
+    cfg.MODEL.RPN.IGNORE_THRESHOLD = 0.5
+
+    cfg.MODEL.DINO = CfgNode(dict(NAME="dinov2", MODEL_NAME="vitb14", OUTPUT="dense", LAYER=-1,
+                                  RETURN_MULTILAYER=False, USE_DEPTH_FUSION=True))
+
+    H = CfgNode()
+    H.NAME = "CubeHead"
+    H.POOLER_RESOLUTION = 7
+    H.POOLER_SAMPLING_RATIO = 0
+    H.POOLER_TYPE = "ROIAlignV2"
+    H.NUM_CONV = 0
+    H.CONV_DIM = 256
+    H.NUM_FC = 2
+    H.FC_DIM = 1024
+    H.USE_TRANSFORMER = False
+    H.Z_TYPE = "direct"
+    H.POSE_TYPE = "6d"
+    H.INVERSE_Z_WEIGHT = False
+    H.VIRTUAL_DEPTH = True
+    H.VIRTUAL_FOCAL = 512.0
+    H.DISENTANGLED_LOSS = True
+    H.CLUSTER_BINS = 1
+    H.ALLOCENTRIC_POSE = True
+    H.CHAMFER_POSE = True
+    H.SHARED_FC = True
+    H.DIMS_PRIORS_ENABLED = True
+    H.DIMS_PRIORS_FUNC = "exp"
+    H.USE_CONFIDENCE = 1.0
+    H.LOSS_W_3D = 1.0
+    H.LOSS_W_XY = 1.0
+    H.LOSS_W_Z = 1.0
+    H.LOSS_W_DIMS = 1.0
+    H.LOSS_W_POSE = 1.0
+    H.LOSS_W_JOINT = 1.0
+    H.SCALE_ROI_BOXES = 0.0
+    cfg.MODEL.ROI_CUBE_HEAD = H
+
+    cfg.MODEL.USE_BN = True
+    cfg.MODEL.STABILIZE = 0.01
+    cfg.MODEL.WEIGHTS_PRETRAIN = ""
+    cfg.TEST.DETECTIONS_PER_IMAGE = 100
+    cfg.TEST.VISIBILITY_THRES = 0.5
+    cfg.TEST.TRUNCATION_THRES = 0.5
+    cfg.TEST.ORACLE2D = True
+    cfg.TEST.CAT_MODE = "base"
+    cfg.INPUT.DEPTH_SIZE = (800, 600)
+
+    # ---- keys that exist only in this build (documented in DESIGN.md) ----
+    # ROIPooler level range: upstream derives it from -log2(1/stride) which is non-integral for
+    # strides 7/14/28; the (unavailable) detectron2 fork changed that rule. SURVEY.md Appendix A5.
+    cfg.MODEL.ROI_HEADS.POOLER_MIN_LEVEL = 2
+    cfg.MODEL.ROI_HEADS.POOLER_MAX_LEVEL = 4
+    # GEMM operand precision of the HIP path: "f16" (one MFMA pass, f32 accumulate) or
+    # "f16x3" (hi/lo split, three passes, ~f32 accuracy).
+    cfg.MODEL.AMD = CfgNode(dict(GEMM_PRECISION="f16", MAX_BATCH=1, MAX_ROIS=1000))
+    return cfg

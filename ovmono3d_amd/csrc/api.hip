@@ -1,0 +1,729 @@
+// C ABI of libovm3d (see include/ovm3d.h): handle, weight packing, forward orchestration.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ovm3d.h"
+#include "kernels.hpp"
+#include "det2d.hpp"
+
+using namespace ovm;
+
+static_assert(sizeof(OvmDet3D) == kRecFloats * 4, "record layout");
+
+namespace {
+
+struct Split {                 // device fp16 split tensor
+  half_t* hi = nullptr; half_t* lo = nullptr;
+};
+
+struct PackedLinear { Split w; float* bias = nullptr; int N = 0, K = 0; };
+
+struct Layer {
+  float *ln1g, *ln1b, *ln2g, *ln2b, *ls1, *ls2;
+  PackedLinear qkv, proj, fc1, fc2;
+};
+
+struct SfpStage {              // 1x1 conv + LN, 3x3 conv + LN
+  PackedLinear c1, c3; float *n1g, *n1b, *n3g, *n3b;
+};
+
+}  // namespace
+
+struct OvmHandle {
+  OvmConfig cfg;
+  int device = 0;
+  std::string err;
+  std::vector<void*> allocs;
+  int G = 0, G2 = 0, T = 0, Tpad = 0, D = 0, C = 0, Kpe = 640, npass = 1;
+  int roiK = 0;
+  // weights
+  PackedLinear pe; float *cls = nullptr, *pos = nullptr;
+  std::vector<Layer> layers;
+  PackedLinear dfuse; bool has_dfuse = false;
+  PackedLinear convt; SfpStage s2, s3, s4;
+  PackedLinear cube_fc1, cube_fc2, cube_out;
+  PackedLinear box_fc1, box_fc2, box_out; bool has_box = false;
+  PackedLinear rpn_conv, rpn_out; bool has_rpn = false;
+  // workspace
+  float* X = nullptr;
+  Split PA, HN, AO, F1, Q, Kx, Vt, DT, DT4, DF, CT;
+  float *dtok = nullptr, *FUS = nullptr;
+  float *T2 = nullptr, *T3 = nullptr, *T4 = nullptr;           // 1x1 / 3x3 conv fp32 outputs (reused)
+  Split P2pad, P3pad, P4pad;                                    // zero-bordered LN(1x1) images
+  float *p2 = nullptr, *p3 = nullptr, *p4 = nullptr;            // final features NHWC fp32
+  Split R2pad, R3pad, R4pad;                                    // zero-bordered fp16 copies of p2..p4 (RPN conv input)
+  Split RF, H1, H2; float* HO = nullptr;
+  float* rec = nullptr; int* keep = nullptr;
+  int *d_bidx = nullptr;
+  ImageDesc* d_imgs = nullptr; ImageMeta* d_meta = nullptr;
+  ImageDesc* h_imgs = nullptr; ImageMeta* h_meta = nullptr;     // pinned staging
+  Det2dWorkspace det;
+  int lastB = 0;
+};
+
+namespace {
+
+#define HCHECK(h, call)                                                                    \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+      return OVM_ERR_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)
+
+#define KCHECK(h, call)                                                                    \
+  do {                                                                                     \
+    int r_ = (call);                                                                       \
+    if (r_ != OVM_OK) {                                                                    \
+      if ((h)->err.empty() || r_ != OVM_ERR_HIP) (h)->err = std::string(#call) + " failed (" + std::to_string(r_) + ")"; \
+      return r_;                                                                           \
+    }                                                                                      \
+  } while (0)
+
+template <typename Tp>
+int dalloc(OvmHandle* h, Tp** p, size_t count, bool zero = false) {
+  void* q = nullptr;
+  size_t bytes = count * sizeof(Tp);
+  if (bytes == 0) bytes = 16;
+  HCHECK(h, hipMalloc(&q, bytes));
+  h->allocs.push_back(q);
+  if (zero) HCHECK(h, hipMemset(q, 0, bytes));
+  *p = (Tp*)q;
+  return OVM_OK;
+}
+
+int salloc(OvmHandle* h, Split* s, size_t count, bool zero = false) {
+  int r = dalloc(h, &s->hi, count, zero);
+  if (r) return r;
+  if (h->npass == 3) return dalloc(h, &s->lo, count, zero);
+  s->lo = nullptr;
+  return OVM_OK;
+}
+
+struct WeightMap {
+  std::map<std::string, const OvmTensor*> m;
+  const OvmTensor* get(const std::string& k) const {
+    auto it = m.find(k);
+    return it == m.end() ? nullptr : it->second;
+  }
+};
+
+int64_t numel(const OvmTensor* t) { int64_t n = 1; for (int i = 0; i < t->ndim; ++i) n *= t->shape[i]; return n; }
+
+int upload_f32(OvmHandle* h, const WeightMap& wm, const std::string& key, int64_t expect, float** out) {
+  const OvmTensor* t = wm.get(key);
+  if (!t) { h->err = "missing weight: " + key; return OVM_ERR_MISSING_WEIGHT; }
+  if (numel(t) != expect) { h->err = "bad shape for " + key; return OVM_ERR_SHAPE; }
+  int r = dalloc(h, out, (size_t)expect);
+  if (r) return r;
+  HCHECK(h, hipMemcpy(*out, t->data, (size_t)expect * 4, hipMemcpyHostToDevice));
+  return OVM_OK;
+}
+
+int upload_vec(OvmHandle* h, const std::vector<float>& v, float** out) {
+  int r = dalloc(h, out, v.size());
+  if (r) return r;
+  HCHECK(h, hipMemcpy(*out, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+  return OVM_OK;
+}
+
+// Pack a host [N][K] fp32 matrix (already in GEMM k-order) into device split fp16 [Npad][Kpad].
+int upload_packed(OvmHandle* h, const std::vector<float>& w, int N, int K, int Kpad, PackedLinear* out) {
+  const int Npad = (N + 127) / 128 * 128;
+  std::vector<half_t> hi((size_t)Npad * Kpad, (half_t)0.f), lo;
+  if (h->npass == 3) lo.assign((size_t)Npad * Kpad, (half_t)0.f);
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k) {
+      const float x = w[(size_t)n * K + k];
+      const half_t hh = (half_t)x;
+      hi[(size_t)n * Kpad + k] = hh;
+      if (h->npass == 3) lo[(size_t)n * Kpad + k] = (half_t)((x - (float)hh) * kLoScale);
+    }
+  int r = dalloc(h, &out->w.hi, hi.size());
+  if (r) return r;
+  HCHECK(h, hipMemcpy(out->w.hi, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
+  if (h->npass == 3) {
+    r = dalloc(h, &out->w.lo, lo.size());
+    if (r) return r;
+    HCHECK(h, hipMemcpy(out->w.lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+  }
+  out->N = N; out->K = Kpad;
+  return OVM_OK;
+}
+
+int get_host(OvmHandle* h, const WeightMap& wm, const std::string& key, int64_t expect, const float** p) {
+  const OvmTensor* t = wm.get(key);
+  if (!t) { h->err = "missing weight: " + key; return OVM_ERR_MISSING_WEIGHT; }
+  if (numel(t) != expect) { h->err = "bad shape for " + key + " (expected " + std::to_string(expect) + ")"; return OVM_ERR_SHAPE; }
+  *p = t->data;
+  return OVM_OK;
+}
+
+// nn.Linear weight [N][K] (+ optional bias) -> packed
+int pack_linear(OvmHandle* h, const WeightMap& wm, const std::string& prefix, int N, int K, PackedLinear* out,
+                bool bias = true, int Kpad = -1) {
+  const float* w; int r = get_host(h, wm, prefix + ".weight", (int64_t)N * K, &w);
+  if (r) return r;
+  std::vector<float> v(w, w + (size_t)N * K);
+  r = upload_packed(h, v, N, K, Kpad < 0 ? K : Kpad, out);
+  if (r) return r;
+  if (bias) return upload_f32(h, wm, prefix + ".bias", N, &out->bias);
+  out->bias = nullptr;
+  return OVM_OK;
+}
+
+// conv weight [Cout][Cin][k][k] -> [Cout][(ky*k+kx)*Cin + c]
+int pack_conv(OvmHandle* h, const WeightMap& wm, const std::string& prefix, int Cout, int Cin, int k, PackedLinear* out,
+              bool bias) {
+  const float* w; int r = get_host(h, wm, prefix + ".weight", (int64_t)Cout * Cin * k * k, &w);
+  if (r) return r;
+  std::vector<float> v((size_t)Cout * Cin * k * k);
+  for (int o = 0; o < Cout; ++o)
+    for (int c = 0; c < Cin; ++c)
+      for (int t = 0; t < k * k; ++t) v[((size_t)o * k * k + t) * Cin + c] = w[((size_t)o * Cin + c) * k * k + t];
+  r = upload_packed(h, v, Cout, Cin * k * k, Cin * k * k, out);
+  if (r) return r;
+  if (bias) return upload_f32(h, wm, prefix + ".bias", Cout, &out->bias);
+  out->bias = nullptr;
+  return OVM_OK;
+}
+
+// FC over pooled RoI features: reference flatten order is (c, ph, pw); ROIAlign here emits (ph, pw, c)
+int pack_roi_fc(OvmHandle* h, const WeightMap& wm, const std::string& prefix, int N, int C, int res, PackedLinear* out) {
+  const int K = C * res * res;
+  const float* w; int r = get_host(h, wm, prefix + ".weight", (int64_t)N * K, &w);
+  if (r) return r;
+  std::vector<float> v((size_t)N * K);
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < C; ++c)
+      for (int s = 0; s < res * res; ++s) v[(size_t)n * K + (size_t)s * C + c] = w[(size_t)n * K + (size_t)c * res * res + s];
+  r = upload_packed(h, v, N, K, K, out);
+  if (r) return r;
+  return upload_f32(h, wm, prefix + ".bias", N, &out->bias);
+}
+
+// several small nn.Linear heads sharing one input, concatenated along N
+int pack_concat(OvmHandle* h, const WeightMap& wm, const std::vector<std::pair<std::string, int>>& parts, int K,
+                PackedLinear* out) {
+  int N = 0; for (auto& p : parts) N += p.second;
+  std::vector<float> v((size_t)N * K), b((size_t)N);
+  int n0 = 0;
+  for (auto& p : parts) {
+    const float *w, *bb;
+    int r = get_host(h, wm, p.first + ".weight", (int64_t)p.second * K, &w); if (r) return r;
+    r = get_host(h, wm, p.first + ".bias", p.second, &bb); if (r) return r;
+    memcpy(&v[(size_t)n0 * K], w, (size_t)p.second * K * 4);
+    memcpy(&b[n0], bb, (size_t)p.second * 4);
+    n0 += p.second;
+  }
+  int r = upload_packed(h, v, N, K, K, out);
+  if (r) return r;
+  return upload_vec(h, b, &out->bias);
+}
+
+int pack_sfp_stage(OvmHandle* h, const WeightMap& wm, const std::string& p1, const std::string& p3, int Cin, SfpStage* s) {
+  const int C = h->C;
+  int r = pack_conv(h, wm, p1, C, Cin, 1, &s->c1, false); if (r) return r;
+  r = upload_f32(h, wm, p1 + ".norm.weight", C, &s->n1g); if (r) return r;
+  r = upload_f32(h, wm, p1 + ".norm.bias", C, &s->n1b); if (r) return r;
+  r = pack_conv(h, wm, p3, C, C, 3, &s->c3, false); if (r) return r;
+  r = upload_f32(h, wm, p3 + ".norm.weight", C, &s->n3g); if (r) return r;
+  return upload_f32(h, wm, p3 + ".norm.bias", C, &s->n3b);
+}
+
+int gemm(OvmHandle* h, const GemmParams& p, int epi, int amode, hipStream_t s) {
+  return launch_gemm(p, h->npass, epi, amode, s);
+}
+
+GemmParams gp_base(const Split& A, int lda, const PackedLinear& W, int M) {
+  GemmParams p; memset(&p, 0, sizeof(p));
+  p.Ahi = A.hi; p.Alo = A.lo; p.lda = lda;
+  p.Whi = W.w.hi; p.Wlo = W.w.lo;
+  p.M = M; p.N = W.N; p.K = W.K; p.bias = W.bias;
+  return p;
+}
+
+void fill_meta(OvmHandle* h, const OvmImage* images, int B) {
+  for (int b = 0; b < B; ++b) {
+    const OvmImage& im = images[b];
+    h->h_imgs[b] = ImageDesc{im.data, im.height, im.width, im.stride_c, im.stride_h, im.stride_w};
+    ImageMeta m;
+    for (int i = 0; i < 9; ++i) m.K[i] = im.K[i];
+    m.ratio = (float)((double)im.orig_height / (double)im.height);     // rcnn3d.py:92 (python float -> fp32 tensor)
+    m.net_h = im.height; m.net_w = im.width; m.orig_h = im.orig_height; m.orig_w = im.orig_width;
+    h->h_meta[b] = m;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ovm_version(void) { return "libovm3d 0.1 (gfx950)"; }
+
+const char* ovm_last_error(const OvmHandle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int ovm_destroy(OvmHandle* h) {
+  if (!h) return OVM_OK;
+  hipSetDevice(h->device);
+  for (void* p : h->allocs) hipFree(p);
+  if (h->h_imgs) hipHostFree(h->h_imgs);
+  if (h->h_meta) hipHostFree(h->h_meta);
+  delete h;
+  return OVM_OK;
+}
+
+int ovm_host_shard_range(int64_t n, int32_t rank, int32_t world, int64_t* begin, int64_t* end) {
+  if (world <= 0 || rank < 0 || rank >= world || n < 0) return OVM_ERR_INVALID;
+  // InferenceSampler._get_local_indices: shard sizes n//W + (r < n%W), contiguous
+  const int64_t q = n / world, r = n % world;
+  const int64_t b = rank * q + (rank < r ? rank : r);
+  *begin = b;
+  *end = b + q + (rank < r ? 1 : 0);
+  return OVM_OK;
+}
+
+// PyTorch upsample_bicubic2d, align_corners=False, scale_factor given (so the source scale is
+// 1/scale_factor, which is what dinov2's +0.1 offset relies on), A = -0.75, border indices clamped.
+int ovm_host_interp_pos_embed(const float* pos, int32_t M, int32_t D, int32_t G, float* out) {
+  if (M <= 0 || D <= 0 || G <= 0) return OVM_ERR_INVALID;
+  memcpy(out, pos, (size_t)D * 4);
+  if (G == M) { memcpy(out + D, pos + D, (size_t)M * M * D * 4); return OVM_OK; }
+  const double sf = ((double)G + 0.1) / (double)M;                  // python: float(w0 + 0.1) / M (double)
+  const float scale = (float)(1.0 / sf);
+  auto coef = [](float t, float* w) {
+    const float A = -0.75f;
+    auto c1 = [&](float x) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; };
+    auto c2 = [&](float x) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; };
+    w[0] = c2(t + 1.f); w[1] = c1(t); w[2] = c1(1.f - t); w[3] = c2(2.f - t);
+  };
+  const float* src = pos + D;
+  float* dst = out + D;
+  for (int oy = 0; oy < G; ++oy) {
+    const float ry = scale * ((float)oy + 0.5f) - 0.5f;
+    const int iy = (int)floorf(ry);
+    float wy[4]; coef(ry - (float)iy, wy);
+    for (int ox = 0; ox < G; ++ox) {
+      const float rx = scale * ((float)ox + 0.5f) - 0.5f;
+      const int ix = (int)floorf(rx);
+      float wx[4]; coef(rx - (float)ix, wx);
+      float* o = dst + ((size_t)oy * G + ox) * D;
+      for (int d = 0; d < D; ++d) o[d] = 0.f;
+      for (int a = 0; a < 4; ++a) {
+        int yy = iy - 1 + a; yy = yy < 0 ? 0 : (yy > M - 1 ? M - 1 : yy);
+        float rowacc_w[4];
+        for (int b = 0; b < 4; ++b) rowacc_w[b] = wx[b];
+        // PyTorch evaluates cubic_interp1d along x first for each of the 4 rows, then along y
+        for (int d = 0; d < D; ++d) {
+          float acc = 0.f;
+          for (int b = 0; b < 4; ++b) {
+            int xx = ix - 1 + b; xx = xx < 0 ? 0 : (xx > M - 1 ? M - 1 : xx);
+            acc += src[((size_t)yy * M + xx) * D + d] * rowacc_w[b];
+          }
+          o[d] += acc * wy[a];
+        }
+      }
+    }
+  }
+  return OVM_OK;
+}
+
+int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights, int32_t device, OvmHandle** out) {
+  if (!cfg || !out) return OVM_ERR_INVALID;
+  OvmHandle* h = new OvmHandle();
+  *out = h;
+  h->cfg = *cfg; h->device = device;
+  const OvmConfig& c = h->cfg;
+  if (c.canvas % 14 != 0 || c.embed_dim % 128 != 0 || c.embed_dim != c.heads * 64 || (c.precision != 1 && c.precision != 3) ||
+      c.fpn_channels % 64 != 0 || c.max_batch < 1 || c.max_rois < 1) {
+    h->err = "invalid config (canvas %14, embed_dim = heads*64 and %128, precision in {1,3}, fpn_channels %64)";
+    return OVM_ERR_INVALID;
+  }
+  HCHECK(h, hipSetDevice(device));
+  h->npass = c.precision;
+  h->D = c.embed_dim; h->C = c.fpn_channels;
+  h->G = c.canvas / 14; h->G2 = h->G * h->G; h->T = h->G2 + 1; h->Tpad = (h->T + 63) / 64 * 64;
+  const int D = h->D, C = h->C, G = h->G, G2 = h->G2, T = h->T, L = c.depth, B = c.max_batch, R = c.max_rois;
+  WeightMap wm;
+  for (int i = 0; i < n_weights; ++i) wm.m[weights[i].name] = &weights[i];
+  int r;
+  const std::string V = "backbone.net.vit.";
+  // ---- patch embed: [D][3][14][14] -> [D][(py*14+px)*3 + c], K padded 588 -> 640
+  {
+    const float* w; r = get_host(h, wm, V + "patch_embed.proj.weight", (int64_t)D * 588, &w); if (r) return r;
+    std::vector<float> v((size_t)D * 588);
+    for (int o = 0; o < D; ++o)
+      for (int ch = 0; ch < 3; ++ch)
+        for (int t = 0; t < 196; ++t) v[(size_t)o * 588 + t * 3 + ch] = w[((size_t)o * 3 + ch) * 196 + t];
+    r = upload_packed(h, v, D, 588, h->Kpe, &h->pe); if (r) return r;
+    r = upload_f32(h, wm, V + "patch_embed.proj.bias", D, &h->pe.bias); if (r) return r;
+    r = upload_f32(h, wm, V + "cls_token", D, &h->cls); if (r) return r;
+    const float* pos; r = get_host(h, wm, V + "pos_embed", (int64_t)(1 + c.pos_grid * c.pos_grid) * D, &pos); if (r) return r;
+    std::vector<float> pi((size_t)T * D);
+    r = ovm_host_interp_pos_embed(pos, c.pos_grid, D, G, pi.data()); if (r) return r;
+    r = upload_vec(h, pi, &h->pos); if (r) return r;
+  }
+  h->layers.resize(L);
+  for (int l = 0; l < L; ++l) {
+    Layer& y = h->layers[l];
+    const std::string P = V + "blocks." + std::to_string(l) + ".";
+    if ((r = upload_f32(h, wm, P + "norm1.weight", D, &y.ln1g))) return r;
+    if ((r = upload_f32(h, wm, P + "norm1.bias", D, &y.ln1b))) return r;
+    if ((r = upload_f32(h, wm, P + "norm2.weight", D, &y.ln2g))) return r;
+    if ((r = upload_f32(h, wm, P + "norm2.bias", D, &y.ln2b))) return r;
+    if ((r = upload_f32(h, wm, P + "ls1.gamma", D, &y.ls1))) return r;
+    if ((r = upload_f32(h, wm, P + "ls2.gamma", D, &y.ls2))) return r;
+    if ((r = pack_linear(h, wm, P + "attn.qkv", 3 * D, D, &y.qkv))) return r;
+    if ((r = pack_linear(h, wm, P + "attn.proj", D, D, &y.proj))) return r;
+    if ((r = pack_linear(h, wm, P + "mlp.fc1", 4 * D, D, &y.fc1))) return r;
+    if ((r = pack_linear(h, wm, P + "mlp.fc2", D, 4 * D, &y.fc2))) return r;
+  }
+  h->has_dfuse = c.use_depth_fusion && wm.get("backbone.net.depth_fusion.weight");
+  if (h->has_dfuse) {
+    if ((r = pack_linear(h, wm, "backbone.net.depth_fusion", D, D + 1, &h->dfuse, true, D + 64))) return r;
+  }
+  // ---- SFP: ConvT [Cin=D][Cout=D/2][2][2] -> [(a*2+b)*Cout + co][c]
+  {
+    const int Co = D / 2;
+    const float* w; r = get_host(h, wm, "backbone.simfp_2.0.weight", (int64_t)D * Co * 4, &w); if (r) return r;
+    std::vector<float> v((size_t)4 * Co * D);
+    for (int ci = 0; ci < D; ++ci)
+      for (int co = 0; co < Co; ++co)
+        for (int q = 0; q < 4; ++q) v[((size_t)q * Co + co) * D + ci] = w[((size_t)ci * Co + co) * 4 + q];
+    r = upload_packed(h, v, 4 * Co, D, D, &h->convt); if (r) return r;
+    r = upload_f32(h, wm, "backbone.simfp_2.0.bias", Co, &h->convt.bias); if (r) return r;
+    if ((r = pack_sfp_stage(h, wm, "backbone.simfp_2.1", "backbone.simfp_2.2", Co, &h->s2))) return r;
+    if ((r = pack_sfp_stage(h, wm, "backbone.simfp_3.0", "backbone.simfp_3.1", D, &h->s3))) return r;
+    if ((r = pack_sfp_stage(h, wm, "backbone.simfp_4.1", "backbone.simfp_4.2", D, &h->s4))) return r;
+  }
+  // ---- heads
+  const int res = c.pooler_res, F = c.fc_dim;
+  h->roiK = C * res * res;
+  const std::string Q = "roi_heads.cube_head.";
+  if ((r = pack_roi_fc(h, wm, Q + "feature_generator.fc1", F, C, res, &h->cube_fc1))) return r;
+  if ((r = pack_linear(h, wm, Q + "feature_generator.fc2", F, F, &h->cube_fc2))) return r;
+  if ((r = pack_concat(h, wm, {{Q + "bbox_3D_center_deltas", 2}, {Q + "bbox_3D_dims", 3}, {Q + "bbox_3D_pose", 6},
+                               {Q + "bbox_3D_center_depth", 1}, {Q + "bbox_3D_uncertainty", 1}}, F, &h->cube_out))) return r;
+  h->has_box = wm.get("roi_heads.box_head.fc1.weight") && wm.get("roi_heads.box_predictor.cls_score.weight");
+  if (h->has_box) {
+    if ((r = pack_roi_fc(h, wm, "roi_heads.box_head.fc1", F, C, res, &h->box_fc1))) return r;
+    if ((r = pack_linear(h, wm, "roi_heads.box_head.fc2", F, F, &h->box_fc2))) return r;
+    if ((r = pack_concat(h, wm, {{"roi_heads.box_predictor.cls_score", c.num_classes + 1},
+                                 {"roi_heads.box_predictor.bbox_pred", c.num_classes * 4}}, F, &h->box_out))) return r;
+  }
+  h->has_rpn = wm.get("proposal_generator.rpn_head.conv.weight") != nullptr;
+  if (h->has_rpn) {
+    const std::string P = "proposal_generator.rpn_head.";
+    if ((r = pack_conv(h, wm, P + "conv", C, C, 3, &h->rpn_conv, true))) return r;
+    // 1x1 convs: objectness [A][C] then deltas [4A][C]
+    if ((r = pack_concat(h, wm, {{P + "objectness_logits", 3}, {P + "anchor_deltas", 12}}, C, &h->rpn_out))) return r;
+  }
+  // ---- workspace
+  const size_t MT = (size_t)B * T, MP = (size_t)B * G2;
+  if ((r = dalloc(h, &h->X, MT * D))) return r;
+  if ((r = salloc(h, &h->PA, MP * h->Kpe))) return r;
+  if ((r = salloc(h, &h->HN, MT * D))) return r;
+  if ((r = salloc(h, &h->AO, MT * D))) return r;
+  if ((r = salloc(h, &h->F1, MT * 4 * D))) return r;
+  if ((r = salloc(h, &h->Q, MT * D))) return r;
+  if ((r = salloc(h, &h->Kx, MT * D))) return r;
+  if ((r = salloc(h, &h->Vt, (size_t)B * D * h->Tpad, true))) return r;
+  if ((r = salloc(h, &h->DT, MP * D))) return r;
+  if ((r = salloc(h, &h->DT4, (size_t)B * (G / 2) * (G / 2) * D))) return r;
+  if (h->has_dfuse) {
+    if ((r = salloc(h, &h->DF, MP * (D + 64)))) return r;
+    if ((r = dalloc(h, &h->dtok, MP))) return r;
+    if ((r = dalloc(h, &h->FUS, MP * D))) return r;
+  }
+  const int G2x = 2 * G, G4 = G / 2;
+  if ((r = salloc(h, &h->CT, (size_t)B * G2x * G2x * (D / 2)))) return r;
+  if ((r = dalloc(h, &h->T2, (size_t)B * G2x * G2x * C))) return r;
+  if ((r = dalloc(h, &h->T3, MP * C))) return r;
+  if ((r = dalloc(h, &h->T4, (size_t)B * G4 * G4 * C))) return r;
+  if ((r = salloc(h, &h->P2pad, (size_t)B * (G2x + 2) * (G2x + 2) * C, true))) return r;
+  if ((r = salloc(h, &h->P3pad, (size_t)B * (G + 2) * (G + 2) * C, true))) return r;
+  if ((r = salloc(h, &h->P4pad, (size_t)B * (G4 + 2) * (G4 + 2) * C, true))) return r;
+  if ((r = dalloc(h, &h->p2, (size_t)B * G2x * G2x * C))) return r;
+  if ((r = dalloc(h, &h->p3, MP * C))) return r;
+  if ((r = dalloc(h, &h->p4, (size_t)B * G4 * G4 * C))) return r;
+  if (h->has_rpn) {
+    if ((r = salloc(h, &h->R2pad, (size_t)B * (G2x + 2) * (G2x + 2) * C, true))) return r;
+    if ((r = salloc(h, &h->R3pad, (size_t)B * (G + 2) * (G + 2) * C, true))) return r;
+    if ((r = salloc(h, &h->R4pad, (size_t)B * (G4 + 2) * (G4 + 2) * C, true))) return r;
+  }
+  const size_t RR = (size_t)R * B;
+  if ((r = salloc(h, &h->RF, RR * h->roiK))) return r;
+  if ((r = salloc(h, &h->H1, RR * F))) return r;
+  if ((r = salloc(h, &h->H2, RR * F))) return r;
+  if ((r = dalloc(h, &h->HO, RR * 256))) return r;
+  if ((r = dalloc(h, &h->rec, RR * kRecFloats))) return r;
+  if ((r = dalloc(h, &h->keep, RR))) return r;
+  if ((r = dalloc(h, &h->d_bidx, RR))) return r;
+  if ((r = dalloc(h, &h->d_imgs, (size_t)B))) return r;
+  if ((r = dalloc(h, &h->d_meta, (size_t)B))) return r;
+  HCHECK(h, hipHostMalloc((void**)&h->h_imgs, sizeof(ImageDesc) * B));
+  HCHECK(h, hipHostMalloc((void**)&h->h_meta, sizeof(ImageMeta) * B));
+  if (h->has_rpn && h->has_box) {
+    std::vector<void*> extra;
+    r = det2d_alloc(&h->det, B, G, C, c.num_classes, R, c.rpn_pre_topk, c.rpn_post_topk, c.detections_per_image, &extra);
+    for (void* p : extra) h->allocs.push_back(p);
+    if (r) { h->err = "det2d workspace allocation failed"; return r; }
+  }
+  HCHECK(h, hipDeviceSynchronize());
+  return OVM_OK;
+}
+
+static int sfp_branch(OvmHandle* h, const Split& in, int lda, int Bn, int Hs, const SfpStage& st, float* T1, const Split& pad,
+                      float* pout, const Split* rpad, hipStream_t s) {
+  const int C = h->C, M = Bn * Hs * Hs;
+  GemmParams p = gp_base(in, lda, st.c1, M);
+  p.C = T1; p.ldc = C;
+  KCHECK(h, gemm(h, p, EPI_STORE, A_ROWMAJOR, s));
+  LnOut o; memset(&o, 0, sizeof(o));
+  o.hi = pad.hi; o.lo = pad.lo; o.ld = C; o.padH = Hs; o.padW = Hs;
+  KCHECK(h, launch_ln_rows(T1, C, M, C, st.n1g, st.n1b, 1e-6f, o, s));
+  GemmParams q; memset(&q, 0, sizeof(q));
+  q.Ahi = pad.hi; q.Alo = pad.lo; q.Whi = st.c3.w.hi; q.Wlo = st.c3.w.lo;
+  q.M = M; q.N = C; q.K = 9 * C; q.cH = Hs; q.cW = Hs; q.cC = C;
+  q.C = T1; q.ldc = C;                                   // 1x1 output already consumed by the LN above
+  KCHECK(h, gemm(h, q, EPI_STORE, A_CONV3X3, s));
+  LnOut o2; memset(&o2, 0, sizeof(o2));
+  o2.f32 = pout; o2.ldf = C;
+  if (rpad && rpad->hi) { o2.hi = rpad->hi; o2.lo = rpad->lo; o2.ld = C; o2.padH = Hs; o2.padW = Hs; }
+  KCHECK(h, launch_ln_rows(T1, C, M, C, st.n3g, st.n3b, 1e-6f, o2, s));
+  return OVM_OK;
+}
+
+int ovm_backbone_forward(OvmHandle* h, const OvmImage* images, int32_t B, const float* prompt_depth, int32_t depth_h,
+                         int32_t depth_w, float* p2, float* p3, float* p4, ovm_stream_t stream) {
+  if (!h) return OVM_ERR_INVALID;
+  h->err.clear();
+  hipStream_t s = (hipStream_t)stream;
+  const OvmConfig& c = h->cfg;
+  if (B < 1 || B > c.max_batch) { h->err = "batch exceeds max_batch"; return OVM_ERR_CAPACITY; }
+  for (int b = 0; b < B; ++b)
+    if (images[b].height > c.canvas || images[b].width > c.canvas || images[b].height < 1 || images[b].width < 1) {
+      h->err = "image larger than SQUARE_PAD canvas"; return OVM_ERR_SHAPE;
+    }
+  HCHECK(h, hipSetDevice(h->device));
+  const int D = h->D, G = h->G, G2 = h->G2, T = h->T, L = c.depth;
+  fill_meta(h, images, B);
+  HCHECK(h, hipMemcpyAsync(h->d_imgs, h->h_imgs, sizeof(ImageDesc) * B, hipMemcpyHostToDevice, s));
+  HCHECK(h, hipMemcpyAsync(h->d_meta, h->h_meta, sizeof(ImageMeta) * B, hipMemcpyHostToDevice, s));
+  h->lastB = B;
+  // ---- patch embed (+ preprocess) ----
+  KCHECK(h, launch_patch_gather(h->d_imgs, B, G, h->Kpe, c.pixel_mean, c.pixel_std, h->PA.hi, h->PA.lo, s));
+  KCHECK(h, launch_cls_init(h->X, h->cls, h->pos, B, T, D, s));
+  {
+    GemmParams p = gp_base(h->PA, h->Kpe, h->pe, B * G2);
+    p.X = h->X; p.ldx = D; p.pos = h->pos; p.G2 = G2; p.T = T;
+    KCHECK(h, gemm(h, p, EPI_PATCH, A_ROWMAJOR, s));
+  }
+  const int M = B * T;
+  for (int l = 0; l < L; ++l) {
+    const Layer& y = h->layers[l];
+    LnOut o; memset(&o, 0, sizeof(o)); o.hi = h->HN.hi; o.lo = h->HN.lo; o.ld = D;
+    KCHECK(h, launch_ln_rows(h->X, D, M, D, y.ln1g, y.ln1b, 1e-6f, o, s));
+    {
+      GemmParams p = gp_base(h->HN, D, y.qkv, M);
+      p.Qhi = h->Q.hi; p.Qlo = h->Q.lo; p.Khi = h->Kx.hi; p.Klo = h->Kx.lo; p.Vhi = h->Vt.hi; p.Vlo = h->Vt.lo;
+      p.T = T; p.Tpad = h->Tpad; p.heads = c.heads; p.qscale = 0.125f;
+      KCHECK(h, gemm(h, p, EPI_QKV, A_ROWMAJOR, s));
+    }
+    {
+      AttnParams a; memset(&a, 0, sizeof(a));
+      a.Qhi = h->Q.hi; a.Qlo = h->Q.lo; a.Khi = h->Kx.hi; a.Klo = h->Kx.lo; a.Vhi = h->Vt.hi; a.Vlo = h->Vt.lo;
+      a.Ohi = h->AO.hi; a.Olo = h->AO.lo; a.ldo = D; a.B = B; a.heads = c.heads; a.T = T; a.Tpad = h->Tpad;
+      KCHECK(h, launch_attention(a, h->npass, s));
+    }
+    {
+      GemmParams p = gp_base(h->AO, D, y.proj, M);
+      p.gamma = y.ls1; p.X = h->X; p.ldx = D;
+      KCHECK(h, gemm(h, p, EPI_RESID, A_ROWMAJOR, s));
+    }
+    KCHECK(h, launch_ln_rows(h->X, D, M, D, y.ln2g, y.ln2b, 1e-6f, o, s));
+    {
+      GemmParams p = gp_base(h->HN, D, y.fc1, M);
+      p.Ohi = h->F1.hi; p.Olo = h->F1.lo; p.ldo = 4 * D;
+      KCHECK(h, gemm(h, p, EPI_GELU, A_ROWMAJOR, s));
+    }
+    {
+      GemmParams p = gp_base(h->F1, 4 * D, y.fc2, M);
+      p.gamma = y.ls2; p.X = h->X; p.ldx = D;
+      KCHECK(h, gemm(h, p, EPI_RESID, A_ROWMAJOR, s));
+    }
+  }
+  // ---- depth fusion at the last block output (reference dino.py:91-105) ----
+  if (prompt_depth) {
+    if (!h->has_dfuse) { h->err = "prompt_depth given but depth_fusion weights absent / disabled"; return OVM_ERR_INVALID; }
+    KCHECK(h, launch_depth_resize(prompt_depth, B, depth_h, depth_w, G, h->dtok, s));
+    KCHECK(h, launch_tokens_cast(h->X, B, T, G2, D, D + 64, h->dtok, h->DF.hi, h->DF.lo, s));
+    GemmParams p = gp_base(h->DF, D + 64, h->dfuse, B * G2);
+    p.C = h->FUS; p.ldc = D;
+    KCHECK(h, gemm(h, p, EPI_STORE, A_ROWMAJOR, s));
+    KCHECK(h, launch_tokens_writeback(h->X, h->FUS, B, T, G2, D, s));
+  }
+  // ---- dense tokens (no final LayerNorm: reference dino.py:88-110) ----
+  KCHECK(h, launch_tokens_cast(h->X, B, T, G2, D, D, nullptr, h->DT.hi, h->DT.lo, s));
+  // ---- SFP (reference dino.py:143-152,208-224; stages nohup.out:565-596) ----
+  const bool rp = h->has_rpn;
+  KCHECK(h, sfp_branch(h, h->DT, D, B, G, h->s3, h->T3, h->P3pad, h->p3, rp ? &h->R3pad : nullptr, s));
+  KCHECK(h, launch_maxpool2(h->DT.hi, h->DT.lo, B, G, D, h->DT4.hi, h->DT4.lo, s));
+  KCHECK(h, sfp_branch(h, h->DT4, D, B, G / 2, h->s4, h->T4, h->P4pad, h->p4, rp ? &h->R4pad : nullptr, s));
+  {
+    GemmParams p = gp_base(h->DT, D, h->convt, B * G2);
+    p.Ohi = h->CT.hi; p.Olo = h->CT.lo; p.G = G; p.Cout = D / 2;
+    KCHECK(h, gemm(h, p, EPI_CONVT, A_ROWMAJOR, s));
+  }
+  KCHECK(h, sfp_branch(h, h->CT, D / 2, B, 2 * G, h->s2, h->T2, h->P2pad, h->p2, rp ? &h->R2pad : nullptr, s));
+  const int C = h->C;
+  if (p2) HCHECK(h, hipMemcpyAsync(p2, h->p2, (size_t)B * 4 * G2 * C * 4, hipMemcpyDeviceToDevice, s));
+  if (p3) HCHECK(h, hipMemcpyAsync(p3, h->p3, (size_t)B * G2 * C * 4, hipMemcpyDeviceToDevice, s));
+  if (p4) HCHECK(h, hipMemcpyAsync(p4, h->p4, (size_t)B * (G / 2) * (G / 2) * C * 4, hipMemcpyDeviceToDevice, s));
+  return OVM_OK;
+}
+
+static void roi_params(OvmHandle* h, RoiParams* rp) {
+  memset(rp, 0, sizeof(*rp));
+  const int G = h->G;
+  rp->feat[0] = h->p2; rp->fh[0] = rp->fw[0] = 2 * G; rp->scale[0] = 1.0f / 7.0f;
+  rp->feat[1] = h->p3; rp->fh[1] = rp->fw[1] = G;     rp->scale[1] = 1.0f / 14.0f;
+  rp->feat[2] = h->p4; rp->fh[2] = rp->fw[2] = G / 2; rp->scale[2] = 1.0f / 28.0f;
+  rp->C = h->C; rp->nlevels = 3; rp->min_level = h->cfg.pooler_min_level; rp->max_level = h->cfg.pooler_max_level;
+  rp->out = h->cfg.pooler_res;
+}
+
+int ovm_cube_forward(OvmHandle* h, const OvmImage* images, int32_t B, const float* boxes, const float* scores,
+                     const int32_t* classes, const int32_t* image_idx, int32_t n, int32_t postprocess, OvmDet3D* out,
+                     int32_t* out_counts, ovm_stream_t stream) {
+  if (!h) return OVM_ERR_INVALID;
+  h->err.clear();
+  hipStream_t s = (hipStream_t)stream;
+  if (B < 1 || B > h->cfg.max_batch) { h->err = "batch exceeds max_batch"; return OVM_ERR_CAPACITY; }
+  if (n > h->cfg.max_rois * h->cfg.max_batch) { h->err = "n exceeds max_rois*max_batch"; return OVM_ERR_CAPACITY; }
+  HCHECK(h, hipSetDevice(h->device));
+  if (n <= 0) {                                       // roi_heads.py:371-372: nothing to do
+    HCHECK(h, hipMemsetAsync(out_counts, 0, sizeof(int) * B, s));
+    return OVM_OK;
+  }
+  fill_meta(h, images, B);
+  HCHECK(h, hipMemcpyAsync(h->d_meta, h->h_meta, sizeof(ImageMeta) * B, hipMemcpyHostToDevice, s));
+  const int F = h->cfg.fc_dim;
+  RoiParams rp; roi_params(h, &rp);
+  rp.boxes = boxes; rp.batch_idx = image_idx; rp.n = n; rp.Ohi = h->RF.hi; rp.Olo = h->RF.lo; rp.ldo = h->roiK;
+  KCHECK(h, launch_roi_align(rp, s));
+  {
+    GemmParams p = gp_base(h->RF, h->roiK, h->cube_fc1, n);
+    p.Ohi = h->H1.hi; p.Olo = h->H1.lo; p.ldo = F; p.relu = 1;
+    KCHECK(h, gemm(h, p, EPI_STORE, A_ROWMAJOR, s));
+  }
+  {
+    GemmParams p = gp_base(h->H1, F, h->cube_fc2, n);
+    p.Ohi = h->H2.hi; p.Olo = h->H2.lo; p.ldo = F; p.relu = 1;
+    KCHECK(h, gemm(h, p, EPI_STORE, A_ROWMAJOR, s));
+  }
+  {
+    GemmParams p = gp_base(h->H2, F, h->cube_out, n);
+    p.C = h->HO; p.ldc = 16;
+    KCHECK(h, gemm(h, p, EPI_STORE, A_ROWMAJOR, s));
+  }
+  CubeDecodeParams cp; memset(&cp, 0, sizeof(cp));
+  cp.head = h->HO; cp.ldh = 16; cp.boxes = boxes; cp.scores = scores; cp.classes = classes; cp.batch_idx = image_idx;
+  cp.meta = h->d_meta; cp.n = n; cp.virtual_focal = h->cfg.virtual_focal; cp.rec = h->rec; cp.keep = h->keep;
+  cp.postprocess = postprocess;
+  KCHECK(h, launch_cube_decode(cp, s));
+  KCHECK(h, launch_compact_records(h->rec, h->keep, n, B, (float*)out, out_counts, s));
+  return OVM_OK;
+}
+
+int ovm_rpn_box_forward(OvmHandle* h, const OvmImage* images, int32_t B, float* boxes, float* scores, int32_t* classes,
+                        int32_t* image_idx, float* scores_full, int32_t* out_counts, ovm_stream_t stream) {
+  if (!h) return OVM_ERR_INVALID;
+  h->err.clear();
+  if (!h->has_rpn || !h->has_box) { h->err = "checkpoint has no RPN / box-head weights"; return OVM_ERR_MISSING_WEIGHT; }
+  if (B < 1 || B > h->cfg.max_batch) { h->err = "batch exceeds max_batch"; return OVM_ERR_CAPACITY; }
+  hipStream_t s = (hipStream_t)stream;
+  HCHECK(h, hipSetDevice(h->device));
+  fill_meta(h, images, B);
+  HCHECK(h, hipMemcpyAsync(h->d_meta, h->h_meta, sizeof(ImageMeta) * B, hipMemcpyHostToDevice, s));
+  Det2dModel m; memset(&m, 0, sizeof(m));
+  m.npass = h->npass; m.B = B; m.G = h->G; m.C = h->C; m.F = h->cfg.fc_dim; m.roiK = h->roiK;
+  m.num_classes = h->cfg.num_classes;
+  m.rpad[0] = {h->R2pad.hi, h->R2pad.lo}; m.rpad[1] = {h->R3pad.hi, h->R3pad.lo}; m.rpad[2] = {h->R4pad.hi, h->R4pad.lo};
+  m.rpn_conv_hi = h->rpn_conv.w.hi; m.rpn_conv_lo = h->rpn_conv.w.lo; m.rpn_conv_bias = h->rpn_conv.bias;
+  m.rpn_out_hi = h->rpn_out.w.hi; m.rpn_out_lo = h->rpn_out.w.lo; m.rpn_out_bias = h->rpn_out.bias;
+  m.fc1_hi = h->box_fc1.w.hi; m.fc1_lo = h->box_fc1.w.lo; m.fc1_bias = h->box_fc1.bias;
+  m.fc2_hi = h->box_fc2.w.hi; m.fc2_lo = h->box_fc2.w.lo; m.fc2_bias = h->box_fc2.bias;
+  m.out_hi = h->box_out.w.hi; m.out_lo = h->box_out.w.lo; m.out_bias = h->box_out.bias;
+  for (int i = 0; i < 3; ++i) { m.anchor_sizes[i] = h->cfg.anchor_sizes[i]; m.anchor_ratios[i] = h->cfg.anchor_ratios[i]; }
+  m.pre_topk = h->cfg.rpn_pre_topk; m.post_topk = h->cfg.rpn_post_topk; m.rpn_nms = h->cfg.rpn_nms_thresh;
+  m.score_thresh = h->cfg.score_thresh; m.nms_thresh = h->cfg.nms_thresh; m.topk = h->cfg.detections_per_image;
+  m.meta = h->d_meta;
+  RoiParams rp; roi_params(h, &rp);
+  m.roi = rp; m.RF = {h->RF.hi, h->RF.lo}; m.H1 = {h->H1.hi, h->H1.lo}; m.H2 = {h->H2.hi, h->H2.lo}; m.HO = h->HO;
+  int r = det2d_forward(m, h->det, boxes, scores, classes, image_idx, scores_full, out_counts, s);
+  if (r) { h->err = "det2d_forward failed (" + std::to_string(r) + ")"; return r; }
+  return OVM_OK;
+}
+
+int64_t ovm_debug_copy(OvmHandle* h, const char* name, float* dst, int64_t capacity, ovm_stream_t stream) {
+  if (!h || !name) return OVM_ERR_INVALID;
+  const int B = h->lastB, G = h->G, C = h->C;
+  const float* src = nullptr; int64_t n = 0;
+  const std::string k(name);
+  if (k == "tokens") { src = h->X; n = (int64_t)B * h->T * h->D; }
+  else if (k == "p2") { src = h->p2; n = (int64_t)B * 4 * G * G * C; }
+  else if (k == "p3") { src = h->p3; n = (int64_t)B * G * G * C; }
+  else if (k == "p4") { src = h->p4; n = (int64_t)B * (G / 2) * (G / 2) * C; }
+  else { h->err = "unknown debug tensor"; return OVM_ERR_INVALID; }
+  if (n > capacity) { h->err = "debug copy capacity too small"; return OVM_ERR_CAPACITY; }
+  if (hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return OVM_ERR_HIP;
+  return n;
+}
+
+// One gather of fixed-width records to rank 0: counts all-gather, then grouped send/recv (a gatherv).
+// Every peer uses its own xGMI link to rank 0's GPU; the payload is ~200 B per detection.
+int ovm_gather_records(void* comm, int32_t rank, int32_t world, const OvmDet3D* send, int32_t n_send, OvmDet3D* recv,
+                       int32_t* counts_all, ovm_stream_t stream) {
+  if (!comm || world < 1 || rank < 0 || rank >= world) return OVM_ERR_INVALID;
+  ncclComm_t cm = (ncclComm_t)comm;
+  hipStream_t s = (hipStream_t)stream;
+  int* d_counts = nullptr;
+  if (hipMalloc((void**)&d_counts, sizeof(int) * (world + 1)) != hipSuccess) return OVM_ERR_HIP;
+  int rc = OVM_OK;
+  do {
+    if (hipMemcpyAsync(d_counts + world, &n_send, sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) { rc = OVM_ERR_HIP; break; }
+    if (ncclAllGather(d_counts + world, d_counts, 1, ncclInt32, cm, s) != ncclSuccess) { rc = OVM_ERR_HIP; break; }
+    if (hipMemcpyAsync(counts_all, d_counts, sizeof(int) * world, hipMemcpyDeviceToHost, s) != hipSuccess) { rc = OVM_ERR_HIP; break; }
+    if (hipStreamSynchronize(s) != hipSuccess) { rc = OVM_ERR_HIP; break; }
+    const size_t rb = sizeof(OvmDet3D);
+    if (ncclGroupStart() != ncclSuccess) { rc = OVM_ERR_HIP; break; }
+    if (rank == 0) {
+      size_t off = 0;
+      for (int r = 0; r < world; ++r) {
+        if (r == 0) {
+          if (n_send > 0) hipMemcpyAsync(recv, send, rb * n_send, hipMemcpyDeviceToDevice, s);
+        } else if (counts_all[r] > 0) {
+          ncclRecv((char*)recv + off * rb, rb * counts_all[r], ncclUint8, r, cm, s);
+        }
+        off += counts_all[r];
+      }
+    } else if (n_send > 0) {
+      ncclSend(send, rb * n_send, ncclUint8, 0, cm, s);
+    }
+    if (ncclGroupEnd() != ncclSuccess) { rc = OVM_ERR_HIP; break; }
+  } while (0);
+  hipStreamSynchronize(s);
+  hipFree(d_counts);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of the OVMono3D-LIFT path.
+// Wave = 64 lanes everywhere; no CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ovm {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Split-precision operand: x ~= hi + lo * 2^-11, hi = fp16(x), lo = fp16((x - hi) * 2^11).
+// One-pass mode (precision "f16") uses hi only; three-pass mode ("f16x3") accumulates
+//   acc0 += Ah*Wh ; acc1 += Al*Wh + Ah*Wl ; C = acc0 + acc1 * 2^-11      (Al*Wl ~ 2^-22 dropped)
+constexpr float kLoScale = 2048.0f;
+constexpr float kLoInv = 1.0f / 2048.0f;
+
+__device__ __forceinline__ void split_f16(float x, half_t& hi, half_t& lo) {
+  hi = (half_t)x;
+  lo = (half_t)((x - (float)hi) * kLoScale);
+}
+
+// 16-byte async global -> LDS copy (global_load_lds_dwordx4). LDS destination is
+// wave-uniform base + lane*16; the per-lane part lives in the global source address.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void*)gsrc,
+      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Bijective XCD-aware remap of a linear workgroup id: blocks that share an XCD (id % 8 under the
+// observed round-robin placement) get a contiguous chunk of the tile space. Speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (bid >> 3);
+}
+
+}  // namespace ovm
+
+#ifndef OVM_OK
+#define OVM_OK 0
+#define OVM_ERR_INVALID (-1)
+#define OVM_ERR_HIP (-2)
+#define OVM_ERR_MISSING_WEIGHT (-3)
+#define OVM_ERR_SHAPE (-4)
+#define OVM_ERR_CAPACITY (-5)
+#endif

@@ -1,0 +1,290 @@
+// MFMA GEMM for gfx950: C[m][n] = sum_k A[m][k] * W[n][k]   (both operands K-contiguous fp16)
+//
+//  * 128x128 block tile, 256 threads = 4 waves in 2(M) x 2(N), each wave 64x64 = 4x4 MFMA tiles of
+//    v_mfma_f32_16x16x32_f16 (W rows on the MFMA "A" side, activation rows on the "B" side, so a
+//    lane's 4 accumulator registers run along n: 16-byte epilogue vectors).
+//  * Operands staged global -> LDS with global_load_lds_dwordx4 (no VGPR round trip), two LDS
+//    stages; swizzle applied on the per-lane SOURCE address and again on the ds_read_b128 address
+//    (LDS image itself is lane-linear, as the DMA requires).
+//  * NPASS=1: plain fp16 operands, fp32 accumulate.  NPASS=3: split operands (hi + lo*2^-11),
+//    three MFMAs per product into two accumulators - fp32-class accuracy at 1/3 of the fp16 rate
+//    (still ~5x the fp32-MFMA rate).
+//  * AMODE selects how a row of A is addressed: dense row-major, or implicit-GEMM 3x3 convolution
+//    over a zero-bordered NHWC fp16 image (k = tap*C + c).
+//  * EPI selects the fused epilogue (bias/LayerScale/residual, GELU, QKV head split with V^T
+//    layout, patch-embed + pos-embed, ConvTranspose 2x2 scatter, generic store).
+#pragma once
+#include "common.hpp"
+
+namespace ovm {
+
+enum AMode { A_ROWMAJOR = 0, A_CONV3X3 = 1 };
+enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_QKV = 3, EPI_PATCH = 4, EPI_CONVT = 5 };
+
+struct GemmParams {
+  const half_t* Ahi; const half_t* Alo; int lda;
+  const half_t* Whi; const half_t* Wlo;          // [Npad][K], Npad multiple of 128, zero rows beyond N
+  int M, N, K;
+  // A_CONV3X3: A is [B][cH+2][cW+2][cC] fp16 with a zero border, m = (b*cH + y)*cW + x
+  int cH, cW, cC;
+  // epilogue operands
+  const float* bias;                              // [N] or null
+  const float* gamma;                             // EPI_RESID: LayerScale [N]
+  float* X; int ldx;                              // EPI_RESID: fp32 residual stream, in place
+  float* C; int ldc;                              // EPI_STORE: fp32 out (or null)
+  half_t* Ohi; half_t* Olo; int ldo;              // EPI_STORE / EPI_GELU / EPI_CONVT: fp16 split out (or null)
+  int relu;
+  // EPI_STORE with padded-NHWC destination for Ohi/Olo (conv input): if padH>0, row m=(b,y,x) goes to
+  // ((b*(padH+2) + y+1)*(padW+2) + x+1)
+  int padH, padW;
+  // EPI_QKV
+  half_t *Qhi, *Qlo, *Khi, *Klo, *Vhi, *Vlo; int T, Tpad, heads; float qscale;
+  // EPI_PATCH: X[(b*T + 1 + p)][n] = acc + bias[n] + pos[(1+p)*N + n],   m = b*G2 + p
+  const float* pos; int G2;
+  // EPI_CONVT: m = (b, i, j) over GxG, n = (a*2 + bb)*Cout + co -> NHWC [B][2G][2G][Cout]
+  int G, Cout;
+};
+
+template <int BK> __device__ __forceinline__ int swz_slot(int row, int chunk);
+// 128-byte rows (BK=64): 8 chunks of 16 B. Conflict-free for ds_read_b128 of 16 or 32 distinct
+// rows at one chunk column (16x16x32 and 32x32x16 operand reads).
+template <> __device__ __forceinline__ int swz_slot<64>(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+// 64-byte rows (BK=32): 4 chunks; g = {0,2,3,1}[(row>>2)&3]
+template <> __device__ __forceinline__ int swz_slot<32>(int row, int chunk) {
+  return chunk ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3);
+}
+
+template <int AMODE>
+__device__ __forceinline__ uint32_t a_row_offset(const GemmParams& p, int m) {
+  if (AMODE == A_ROWMAJOR) return (uint32_t)m * (uint32_t)p.lda;
+  const int x = m % p.cW; const int t = m / p.cW; const int y = t % p.cH; const int b = t / p.cH;
+  return (uint32_t)(((b * (p.cH + 2) + y) * (p.cW + 2) + x) * p.cC);
+}
+template <int AMODE>
+__device__ __forceinline__ uint32_t a_k_offset(const GemmParams& p, int k0) {
+  if (AMODE == A_ROWMAJOR) return (uint32_t)k0;
+  const int tap = k0 / p.cC, c0 = k0 - tap * p.cC;
+  const int dy = tap / 3, dx = tap - dy * 3;
+  return (uint32_t)((dy * (p.cW + 2) + dx) * p.cC + c0);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int EPI>
+__device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32x4 v) {
+  // v[r] belongs to (m, n + r); n is a multiple of 4; caller guarantees m < M; n + r may be >= N.
+  if (n >= p.N) return;
+  float b4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b4[r] = (n + r < p.N) ? p.bias[n + r] : 0.f;
+  }
+  const bool full = (n + 3 < p.N);
+  if (EPI == EPI_RESID) {
+    float* x = p.X + (size_t)m * p.ldx + n;
+    if (full) {
+      f32x4 xv = *(const f32x4*)x;
+      const f32x4 g = *(const f32x4*)(p.gamma + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xv[r] += g[r] * (v[r] + b4[r]);
+      *(f32x4*)x = xv;
+    } else {
+      for (int r = 0; r < 4 && n + r < p.N; ++r) x[r] += p.gamma[n + r] * (v[r] + b4[r]);
+    }
+  } else if (EPI == EPI_GELU) {
+    half4 h, l;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { half_t hh, ll; split_f16(gelu_erf(v[r] + b4[r]), hh, ll); h[r] = hh; l[r] = ll; }
+    const size_t o = (size_t)m * p.ldo + n;
+    *(half4*)(p.Ohi + o) = h;
+    if (p.Olo) *(half4*)(p.Olo + o) = l;
+  } else if (EPI == EPI_QKV) {
+    const int Dm = p.N / 3;
+    const int which = n / Dm;
+    const int f = n - which * Dm;
+    const int head = f >> 6, d = f & 63;
+    const int b = m / p.T, t = m - b * p.T;
+    half4 h, l;
+    const float sc = (which == 0) ? p.qscale : 1.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { half_t hh, ll; split_f16((v[r] + b4[r]) * sc, hh, ll); h[r] = hh; l[r] = ll; }
+    if (which < 2) {
+      const size_t o = ((size_t)(b * p.heads + head) * p.T + t) * 64 + d;
+      half_t* dh = (which == 0) ? p.Qhi : p.Khi;
+      half_t* dl = (which == 0) ? p.Qlo : p.Klo;
+      *(half4*)(dh + o) = h;
+      if (dl) *(half4*)(dl + o) = l;
+    } else {
+      // V^T [b][head][d][Tpad], token order permuted inside each group of 16 (bits 2<->3 swapped)
+      // so that the PV MFMA's A fragment (k order 4h+{0..3}, 8+4h+{0..3}) is one 16-byte LDS read.
+      const int tp = (t & ~15) | (t & 3) | ((t & 4) << 1) | ((t & 8) >> 1);
+      const size_t o = ((size_t)(b * p.heads + head) * 64 + d) * p.Tpad + tp;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p.Vhi[o + (size_t)r * p.Tpad] = h[r];
+        if (p.Vlo) p.Vlo[o + (size_t)r * p.Tpad] = l[r];
+      }
+    }
+  } else if (EPI == EPI_PATCH) {
+    const int b = m / p.G2, pp = m - b * p.G2;
+    float* x = p.X + ((size_t)b * p.T + 1 + pp) * p.ldx + n;
+    const float* ps = p.pos + (size_t)(1 + pp) * p.N + n;
+    for (int r = 0; r < 4 && n + r < p.N; ++r) x[r] = v[r] + b4[r] + ps[r];
+  } else if (EPI == EPI_CONVT) {
+    const int q = n / p.Cout, co = n - q * p.Cout;       // q = a*2 + bb; Cout % 4 == 0
+    const int a = q >> 1, bb = q & 1;
+    const int j = m % p.G; const int t = m / p.G; const int i = t % p.G; const int b = t / p.G;
+    const size_t o = (((size_t)b * 2 * p.G + 2 * i + a) * 2 * p.G + 2 * j + bb) * p.Cout + co;
+    half4 h, l;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float bv = p.bias ? p.bias[co + r] : 0.f;
+      half_t hh, ll; split_f16(v[r] + bv, hh, ll); h[r] = hh; l[r] = ll;
+    }
+    *(half4*)(p.Ohi + o) = h;
+    if (p.Olo) *(half4*)(p.Olo + o) = l;
+  } else {  // EPI_STORE
+    float o4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { o4[r] = v[r] + b4[r]; if (p.relu) o4[r] = fmaxf(o4[r], 0.f); }
+    if (p.C) {
+      float* c = p.C + (size_t)m * p.ldc + n;
+      for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = o4[r];
+    }
+    if (p.Ohi) {
+      size_t row = (size_t)m;
+      if (p.padH > 0) {
+        const int x = m % p.padW; const int t = m / p.padW; const int y = t % p.padH; const int b = t / p.padH;
+        row = ((size_t)b * (p.padH + 2) + y + 1) * (p.padW + 2) + x + 1;
+      }
+      const size_t o = row * p.ldo + n;
+      for (int r = 0; r < 4 && n + r < p.N; ++r) {
+        half_t hh, ll; split_f16(o4[r], hh, ll);
+        p.Ohi[o + r] = hh;
+        if (p.Olo) p.Olo[o + r] = ll;
+      }
+    }
+  }
+}
+
+template <int NPASS, int BK, int EPI, int AMODE>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWB = BK * 2;                    // bytes per LDS row
+  constexpr int PART = 128 * ROWB;                // bytes per operand part
+  constexpr int NPART = (NPASS == 3) ? 4 : 2;     // Ahi, Whi, (Alo, Wlo)
+  constexpr int STAGE = PART * NPART;
+  constexpr int ROWS_PER_INSTR = 1024 / ROWB;     // rows one wave-wide DMA covers (8 or 16)
+  constexpr int CH = ROWB / 16;                   // 16-byte chunks per row (8 or 4)
+  constexpr int INSTR_PER_WAVE = 128 / ROWS_PER_INSTR / 4;   // per part (4 or 2)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_m = (p.M + 127) >> 7;
+  const int ntile_n = gridDim.x / tiles_m;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid / tiles_m, tm = bid - tn * tiles_m;
+  (void)ntile_n;
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- per-lane DMA source offsets (elements), fixed over k ----
+  uint32_t aoff[INSTR_PER_WAVE], woff[INSTR_PER_WAVE];
+#pragma unroll
+  for (int t = 0; t < INSTR_PER_WAVE; ++t) {
+    const int instr = wave + 4 * t;
+    const int row = instr * ROWS_PER_INSTR + lane / CH;
+    const int slot = lane % CH;
+    const int chunk = swz_slot<BK>(row, slot);      // involution: slot -> source chunk
+    int m = m0 + row; if (m > p.M - 1) m = p.M - 1;
+    aoff[t] = a_row_offset<AMODE>(p, m) + chunk * 8;
+    woff[t] = (uint32_t)(n0 + row) * (uint32_t)p.K + chunk * 8;
+  }
+
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * STAGE;
+    const uint32_t ak = a_k_offset<AMODE>(p, kt * BK);
+    const uint32_t wk = (uint32_t)(kt * BK);
+#pragma unroll
+    for (int t = 0; t < INSTR_PER_WAVE; ++t) {
+      const int instr = wave + 4 * t;
+      char* dst = base + instr * 1024;
+      glds16(p.Ahi + aoff[t] + ak, dst);
+      glds16(p.Whi + woff[t] + wk, dst + PART);
+      if (NPASS == 3) {
+        glds16(p.Alo + aoff[t] + ak, dst + 2 * PART);
+        glds16(p.Wlo + woff[t] + wk, dst + 3 * PART);
+      }
+    }
+  };
+
+  f32x4 acc0[4][4], acc1[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc0[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* base = smem + cur * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      half8 ah[4], wh[4], al[4], wl[4];
+      const int chunk = kk * 4 + fq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ra = wm * 64 + i * 16 + fr;
+        const int rw = wn * 64 + i * 16 + fr;
+        const int oa = ra * ROWB + swz_slot<BK>(ra, chunk) * 16;
+        const int ow = rw * ROWB + swz_slot<BK>(rw, chunk) * 16;
+        ah[i] = *(const half8*)(base + oa);
+        wh[i] = *(const half8*)(base + PART + ow);
+        if (NPASS == 3) {
+          al[i] = *(const half8*)(base + 2 * PART + oa);
+          wl[i] = *(const half8*)(base + 3 * PART + ow);
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          acc0[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ni], ah[mi], acc0[ni][mi], 0, 0, 0);
+          if (NPASS == 3) {
+            acc1[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ni], ah[mi], acc1[ni][mi], 0, 0, 0);
+            acc1[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ni], al[mi], acc1[ni][mi], 0, 0, 0);
+          }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane holds (m = m0+wm*64+mi*16+fr, n = n0+wn*64+ni*16+fq*4 .. +3)
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = m0 + wm * 64 + mi * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wn * 64 + ni * 16 + fq * 4;
+      f32x4 v = acc0[ni][mi];
+      if (NPASS == 3) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += acc1[ni][mi][r] * kLoInv;
+      }
+      epilogue4<EPI>(p, m, n, v);
+    }
+  }
+}
+
+// Host launcher (defined in gemm.hip). npass in {1,3}.
+int launch_gemm(const GemmParams& p, int npass, int epi, int amode, hipStream_t stream);
+
+}  // namespace ovm

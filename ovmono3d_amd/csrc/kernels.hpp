@@ -1,0 +1,75 @@
+// Declarations of every kernel launcher of the path (definitions in the .hip files).
+#pragma once
+#include "common.hpp"
+#include "gemm.hpp"
+
+namespace ovm {
+
+struct ImageDesc {             // one input image as the caller holds it in HBM
+  const uint8_t* data;
+  int H, W;                    // network-resolution size (after ResizeShortestEdge)
+  int64_t sC, sH, sW;          // element strides (CHW: HW, W, 1; NHWC: 1, 3W, 3)
+};
+
+struct LnOut {
+  half_t* hi; half_t* lo; int ld;   // fp16 split output (row stride ld), or null
+  float* f32; int ldf;              // fp32 output, or null
+  int padH, padW;                   // >0: hi/lo rows go to the interior of a zero-bordered NHWC image
+};
+
+struct AttnParams {
+  const half_t *Qhi, *Qlo, *Khi, *Klo, *Vhi, *Vlo;   // Q,K [B][h][T][64]; V^T [B][h][64][Tpad] (permuted tokens)
+  half_t *Ohi, *Olo; int ldo;                        // out rows b*T + t, column head*64 + d
+  int B, heads, T, Tpad;
+};
+
+struct RoiParams {
+  const float* feat[3]; int fh[3], fw[3]; float scale[3];   // NHWC fp32 levels
+  int C, nlevels, min_level, max_level, out;                 // out = pooled resolution (7)
+  const float* boxes;                                        // [n][4] xyxy network res
+  const int* batch_idx;                                      // [n]
+  int n;
+  half_t *Ohi, *Olo; int ldo;                                // [n][out*out*C], (ph, pw, c) order
+};
+
+struct ImageMeta {             // per image, device resident
+  float K[9];
+  float ratio;                 // im_scales_ratio = orig_h / net_h     (rcnn3d.py:92)
+  int net_h, net_w, orig_h, orig_w;
+};
+
+constexpr int kRecFloats = 48;
+// Detection record (48 x 4 bytes): [0:4] box xyxy (original res after postprocess), [4] fused score,
+// [5] class (int32 bits), [6:30] bbox3D 8x3, [30:33] center_cam, [33:35] center_2D, [35:38] dims (W,H,L),
+// [38:47] pose 3x3, [47] image index (int32 bits)
+
+struct CubeDecodeParams {
+  const float* head;  int ldh;     // [n][>=13]: deltas(2) dims(3) pose6(6) z(1) uncert(1)
+  const float* boxes;              // [n][4] network res
+  const float* scores;             // [n] 2D scores
+  const int* classes;              // [n]
+  const int* batch_idx;            // [n]
+  const ImageMeta* meta;           // [B]
+  int n; float virtual_focal;
+  int postprocess;                 // 1: detector_postprocess (rescale+clip+non-empty); 0: keep network-res boxes
+  float* rec;                      // [n][48]
+  int* keep;                       // [n] 1 if the post-processed 2D box is non-empty
+};
+
+int launch_patch_gather(const ImageDesc* d_imgs, int B, int G, int Kpad, const float* mean, const float* stdv,
+                        half_t* Ahi, half_t* Alo, hipStream_t s);
+int launch_cls_init(float* X, const float* cls, const float* pos, int B, int T, int D, hipStream_t s);
+int launch_ln_rows(const float* X, int ldx, int M, int D, const float* gamma, const float* beta, float eps,
+                   const LnOut& o, hipStream_t s);
+int launch_tokens_cast(const float* X, int B, int T, int G2, int D, int ldo, const float* depth_tok,
+                       half_t* Ohi, half_t* Olo, hipStream_t s);
+int launch_tokens_writeback(float* X, const float* F, int B, int T, int G2, int D, hipStream_t s);
+int launch_maxpool2(const half_t* Ihi, const half_t* Ilo, int B, int G, int D, half_t* Ohi, half_t* Olo, hipStream_t s);
+int launch_depth_resize(const float* Dp, int B, int Hd, int Wd, int G, float* out, hipStream_t s);
+int launch_zero(void* p, size_t bytes, hipStream_t s);
+int launch_attention(const AttnParams& p, int npass, hipStream_t s);
+int launch_roi_align(const RoiParams& p, hipStream_t s);
+int launch_cube_decode(const CubeDecodeParams& p, hipStream_t s);
+int launch_compact_records(const float* rec, const int* keep, int n, int B, float* out, int* counts, hipStream_t s);
+
+}  // namespace ovm

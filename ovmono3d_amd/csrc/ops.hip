@@ -1,0 +1,158 @@
+// Kernel-level C entry points (parity tests / micro-benchmarks): thin adapters that convert fp32 test
+// tensors to the split-fp16 layouts and launch the same kernels the model path uses.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <vector>
+#include "../../include/ovm3d.h"
+#include "kernels.hpp"
+#include "det2d.hpp"
+
+using namespace ovm;
+
+namespace {
+__global__ void split_kernel(const float* __restrict__ x, int64_t n, half_t* __restrict__ hi, half_t* __restrict__ lo) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  half_t h, l; split_f16(x[i], h, l);
+  hi[i] = h;
+  if (lo) lo[i] = l;
+}
+// qkv [B*T][3D] fp32 (as nn.Linear emits it) -> Q (pre-scaled), K, V^T split layouts of the attention kernel
+__global__ void qkv_layout_kernel(const float* __restrict__ qkv, int B, int T, int Tpad, int heads,
+                                  half_t* Qh, half_t* Ql, half_t* Kh, half_t* Kl, half_t* Vh, half_t* Vl) {
+  const int D = heads * 64;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * T * 3 * D;
+  if (i >= total) return;
+  const int n = (int)(i % (3 * D)); const int64_t m = i / (3 * D);
+  const int b = (int)(m / T), t = (int)(m - (int64_t)b * T);
+  const int which = n / D, f = n - which * D, head = f >> 6, d = f & 63;
+  float v = qkv[i]; if (which == 0) v *= 0.125f;
+  half_t h, l; split_f16(v, h, l);
+  if (which < 2) {
+    const size_t o = ((size_t)(b * heads + head) * T + t) * 64 + d;
+    if (which == 0) { Qh[o] = h; if (Ql) Ql[o] = l; } else { Kh[o] = h; if (Kl) Kl[o] = l; }
+  } else {
+    const int tp = (t & ~15) | (t & 3) | ((t & 4) << 1) | ((t & 8) >> 1);
+    const size_t o = ((size_t)(b * heads + head) * 64 + d) * Tpad + tp;
+    Vh[o] = h; if (Vl) Vl[o] = l;
+  }
+}
+__global__ void join_kernel(const half_t* __restrict__ hi, const half_t* __restrict__ lo, int64_t n, float* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  y[i] = (float)hi[i] + (lo ? (float)lo[i] * kLoInv : 0.f);
+}
+struct Tmp {
+  std::vector<void*> p;
+  template <typename Tp> Tp* get(size_t n, bool zero = false) {
+    void* q = nullptr;
+    if (hipMalloc(&q, n * sizeof(Tp) + 16) != hipSuccess) return nullptr;
+    if (zero) hipMemset(q, 0, n * sizeof(Tp) + 16);
+    p.push_back(q);
+    return (Tp*)q;
+  }
+  ~Tmp() { for (void* q : p) hipFree(q); }
+};
+}  // namespace
+
+extern "C" {
+
+int ovm_op_split_f16(const float* x, int64_t n, uint16_t* hi, uint16_t* lo, ovm_stream_t stream) {
+  if (n <= 0) return OVM_OK;
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, (half_t*)hi, (half_t*)lo);
+  return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
+
+// C[M][N] = A[M][K] W[N][K]^T (+bias)(+relu). W must be padded to a multiple of 128 rows by the caller.
+int ovm_op_gemm(const uint16_t* a_hi, const uint16_t* a_lo, int32_t lda, const uint16_t* w_hi, const uint16_t* w_lo,
+                int32_t M, int32_t N, int32_t K, const float* bias, int32_t relu, float* c, int32_t ldc,
+                int32_t precision, ovm_stream_t stream) {
+  GemmParams p; memset(&p, 0, sizeof(p));
+  p.Ahi = (const half_t*)a_hi; p.Alo = (const half_t*)a_lo; p.lda = lda;
+  p.Whi = (const half_t*)w_hi; p.Wlo = (const half_t*)w_lo;
+  p.M = M; p.N = N; p.K = K; p.bias = bias; p.relu = relu; p.C = c; p.ldc = ldc;
+  return launch_gemm(p, precision, EPI_STORE, A_ROWMAJOR, (hipStream_t)stream);
+}
+
+int ovm_op_layernorm(const float* x, int32_t M, int32_t D, const float* gamma, const float* beta, float eps, float* y,
+                     ovm_stream_t stream) {
+  LnOut o; memset(&o, 0, sizeof(o)); o.f32 = y; o.ldf = D;
+  return launch_ln_rows(x, D, M, D, gamma, beta, eps, o, (hipStream_t)stream);
+}
+
+// qkv [B*T][3*heads*64] fp32 -> out [B*T][heads*64] fp32 (synchronous helper: allocates scratch)
+int ovm_op_attention(const float* qkv, int32_t B, int32_t T, int32_t heads, float* out, int32_t precision, ovm_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int D = heads * 64, Tpad = (T + 63) / 64 * 64;
+  const size_t nqk = (size_t)B * T * D, nv = (size_t)B * D * Tpad;
+  Tmp tmp;
+  half_t *Qh = tmp.get<half_t>(nqk), *Kh = tmp.get<half_t>(nqk), *Vh = tmp.get<half_t>(nv, true), *Oh = tmp.get<half_t>(nqk);
+  half_t *Ql = nullptr, *Kl = nullptr, *Vl = nullptr, *Ol = nullptr;
+  if (precision == 3) { Ql = tmp.get<half_t>(nqk); Kl = tmp.get<half_t>(nqk); Vl = tmp.get<half_t>(nv, true); Ol = tmp.get<half_t>(nqk); }
+  if (!Qh || !Kh || !Vh || !Oh) return OVM_ERR_HIP;
+  const int64_t total = (int64_t)B * T * 3 * D;
+  hipLaunchKernelGGL(qkv_layout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, qkv, B, T, Tpad, heads, Qh, Ql, Kh, Kl, Vh, Vl);
+  AttnParams a; memset(&a, 0, sizeof(a));
+  a.Qhi = Qh; a.Qlo = Ql; a.Khi = Kh; a.Klo = Kl; a.Vhi = Vh; a.Vlo = Vl; a.Ohi = Oh; a.Olo = Ol; a.ldo = D;
+  a.B = B; a.heads = heads; a.T = T; a.Tpad = Tpad;
+  int r = launch_attention(a, precision, s);
+  if (r) return r;
+  hipLaunchKernelGGL(join_kernel, dim3((unsigned)((nqk + 255) / 256)), dim3(256), 0, s, Oh, Ol, (int64_t)nqk, out);
+  if (hipStreamSynchronize(s) != hipSuccess) return OVM_ERR_HIP;
+  return OVM_OK;
+}
+
+int ovm_op_roi_align(const float* p2, const float* p3, const float* p4, const int32_t* hw, const float* scales, int32_t C,
+                     int32_t out_res, int32_t min_level, int32_t max_level, const float* boxes, const int32_t* image_idx,
+                     int32_t n, float* out, ovm_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= 0) return OVM_OK;
+  Tmp tmp;
+  const size_t ne = (size_t)n * out_res * out_res * C;
+  half_t *hi = tmp.get<half_t>(ne), *lo = tmp.get<half_t>(ne);
+  if (!hi || !lo) return OVM_ERR_HIP;
+  RoiParams rp; memset(&rp, 0, sizeof(rp));
+  const float* f[3] = {p2, p3, p4};
+  int nl = 0;
+  for (int i = 0; i < 3; ++i) if (f[i]) { rp.feat[nl] = f[i]; rp.fh[nl] = hw[2 * i]; rp.fw[nl] = hw[2 * i + 1]; rp.scale[nl] = scales[i]; ++nl; }
+  rp.C = C; rp.nlevels = nl; rp.min_level = min_level; rp.max_level = max_level; rp.out = out_res;
+  rp.boxes = boxes; rp.batch_idx = image_idx; rp.n = n; rp.Ohi = hi; rp.Olo = lo; rp.ldo = out_res * out_res * C;
+  int r = launch_roi_align(rp, s);
+  if (r) return r;
+  hipLaunchKernelGGL(join_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, hi, lo, (int64_t)ne, out);
+  if (hipStreamSynchronize(s) != hipSuccess) return OVM_ERR_HIP;
+  return OVM_OK;
+}
+
+int ovm_op_cube_decode(const float* head13, int32_t ld, const float* boxes, const float* scores, const int32_t* classes,
+                       const int32_t* image_idx, const OvmImage* images, int32_t B, int32_t n, float virtual_focal,
+                       int32_t postprocess, OvmDet3D* rec, int32_t* keep, ovm_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= 0) return OVM_OK;
+  std::vector<ImageMeta> hm(B);
+  for (int b = 0; b < B; ++b) {
+    for (int i = 0; i < 9; ++i) hm[b].K[i] = images[b].K[i];
+    hm[b].ratio = (float)((double)images[b].orig_height / (double)images[b].height);
+    hm[b].net_h = images[b].height; hm[b].net_w = images[b].width;
+    hm[b].orig_h = images[b].orig_height; hm[b].orig_w = images[b].orig_width;
+  }
+  Tmp tmp;
+  ImageMeta* dm = tmp.get<ImageMeta>(B);
+  if (!dm) return OVM_ERR_HIP;
+  if (hipMemcpy(dm, hm.data(), sizeof(ImageMeta) * B, hipMemcpyHostToDevice) != hipSuccess) return OVM_ERR_HIP;
+  CubeDecodeParams cp; memset(&cp, 0, sizeof(cp));
+  cp.head = head13; cp.ldh = ld; cp.boxes = boxes; cp.scores = scores; cp.classes = classes; cp.batch_idx = image_idx;
+  cp.meta = dm; cp.n = n; cp.virtual_focal = virtual_focal; cp.rec = (float*)rec; cp.keep = keep; cp.postprocess = postprocess;
+  int r = launch_cube_decode(cp, s);
+  if (r) return r;
+  if (hipStreamSynchronize(s) != hipSuccess) return OVM_ERR_HIP;
+  return OVM_OK;
+}
+
+int ovm_op_nms(const float* boxes, const float* scores, int32_t n, float thresh, int32_t* keep_idx, int32_t* n_keep,
+               ovm_stream_t stream) {
+  return launch_nms_single(boxes, scores, n, thresh, keep_idx, n_keep, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,140 @@
+"""ctypes binding of libovm3d.so (the C ABI declared in include/ovm3d.h).
+
+The library is built in-tree by ``ovmono3d_amd/csrc/build.sh`` (``__graft_entry__.build()``).
+There is no CPU or PyTorch fallback: if the shared object is missing or fails to load,
+importing the native path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libovm3d.so")
+
+OVM_REC_FLOATS = 48
+
+
+class OvmConfig(C.Structure):
+    _fields_ = [
+        ("embed_dim", C.c_int32), ("depth", C.c_int32), ("heads", C.c_int32),
+        ("pos_grid", C.c_int32), ("canvas", C.c_int32), ("fpn_channels", C.c_int32),
+        ("use_depth_fusion", C.c_int32),
+        ("pixel_mean", C.c_float * 3), ("pixel_std", C.c_float * 3),
+        ("num_classes", C.c_int32), ("fc_dim", C.c_int32), ("pooler_res", C.c_int32),
+        ("pooler_min_level", C.c_int32), ("pooler_max_level", C.c_int32),
+        ("virtual_focal", C.c_float),
+        ("anchor_sizes", C.c_float * 3), ("anchor_ratios", C.c_float * 3),
+        ("rpn_pre_topk", C.c_int32), ("rpn_post_topk", C.c_int32), ("rpn_nms_thresh", C.c_float),
+        ("score_thresh", C.c_float), ("nms_thresh", C.c_float), ("detections_per_image", C.c_int32),
+        ("precision", C.c_int32), ("max_batch", C.c_int32), ("max_rois", C.c_int32),
+    ]
+
+
+class OvmTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
+
+
+class OvmImage(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("height", C.c_int32), ("width", C.c_int32),
+                ("stride_c", C.c_int64), ("stride_h", C.c_int64), ("stride_w", C.c_int64),
+                ("orig_height", C.c_int32), ("orig_width", C.c_int32), ("K", C.c_float * 9)]
+
+
+EXPORTS = [
+    "ovm_create", "ovm_destroy", "ovm_last_error", "ovm_version", "ovm_backbone_forward", "ovm_cube_forward",
+    "ovm_rpn_box_forward", "ovm_gather_records", "ovm_host_interp_pos_embed", "ovm_host_shard_range",
+    "ovm_op_split_f16", "ovm_op_gemm", "ovm_op_layernorm", "ovm_op_attention", "ovm_op_roi_align",
+    "ovm_op_cube_decode", "ovm_op_nms", "ovm_debug_copy",
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libovm3d.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with ovmono3d_amd/csrc/build.sh (or __graft_entry__.build()). "
+            "The native HIP path has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    lib.ovm_create.argtypes = [C.POINTER(OvmConfig), C.POINTER(OvmTensor), i32, i32, C.POINTER(vp)]
+    lib.ovm_destroy.argtypes = [vp]
+    lib.ovm_last_error.argtypes = [vp]
+    lib.ovm_last_error.restype = C.c_char_p
+    lib.ovm_version.restype = C.c_char_p
+    lib.ovm_backbone_forward.argtypes = [vp, C.POINTER(OvmImage), i32, vp, i32, i32, vp, vp, vp, vp]
+    lib.ovm_cube_forward.argtypes = [vp, C.POINTER(OvmImage), i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
+    lib.ovm_rpn_box_forward.argtypes = [vp, C.POINTER(OvmImage), i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.ovm_gather_records.argtypes = [vp, i32, i32, vp, i32, vp, C.POINTER(i32), vp]
+    lib.ovm_host_interp_pos_embed.argtypes = [vp, i32, i32, i32, vp]
+    lib.ovm_host_shard_range.argtypes = [i64, i32, i32, C.POINTER(i64), C.POINTER(i64)]
+    lib.ovm_op_split_f16.argtypes = [vp, i64, vp, vp, vp]
+    lib.ovm_op_gemm.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, vp, i32, vp, i32, i32, vp]
+    lib.ovm_op_layernorm.argtypes = [vp, i32, i32, vp, vp, f32, vp, vp]
+    lib.ovm_op_attention.argtypes = [vp, i32, i32, i32, vp, i32, vp]
+    lib.ovm_op_roi_align.argtypes = [vp, vp, vp, C.POINTER(i32), C.POINTER(f32), i32, i32, i32, i32, vp, vp, i32, vp, vp]
+    lib.ovm_op_cube_decode.argtypes = [vp, i32, vp, vp, vp, vp, C.POINTER(OvmImage), i32, i32, f32, i32, vp, vp, vp]
+    lib.ovm_op_nms.argtypes = [vp, vp, i32, f32, vp, vp, vp]
+    lib.ovm_debug_copy.argtypes = [vp, C.c_char_p, vp, i64, vp]
+    lib.ovm_debug_copy.restype = i64
+    for name in EXPORTS:
+        if name not in ("ovm_last_error", "ovm_version", "ovm_debug_copy"):
+            getattr(lib, name).restype = i32
+    _lib = lib
+    return lib
+
+
+class OvmError(RuntimeError):
+    pass
+
+
+def check(rc: int, handle=None, what: str = "") -> None:
+    if rc == 0:
+        return
+    msg = ""
+    if handle:
+        msg = (load().ovm_last_error(handle) or b"").decode()
+    raise OvmError(f"{what} failed with code {rc}: {msg}")
+
+
+def make_tensor_table(state_dict: Dict[str, "np.ndarray"]):
+    """state_dict values: contiguous float32 numpy arrays (host). Returns (ctypes array, keepalive)."""
+    items = list(state_dict.items())
+    arr = (OvmTensor * len(items))()
+    keep = []
+    for i, (k, v) in enumerate(items):
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        if v.ndim > 4:
+            raise ValueError(f"{k}: more than 4 dims")
+        kb = k.encode()
+        keep.append((kb, v))
+        arr[i].name = kb
+        arr[i].data = v.ctypes.data
+        arr[i].ndim = v.ndim
+        for d in range(v.ndim):
+            arr[i].shape[d] = v.shape[d]
+    return arr, keep
+
+
+def shard_range(n: int, rank: int, world: int):
+    b, e = C.c_int64(), C.c_int64()
+    check(load().ovm_host_shard_range(n, rank, world, C.byref(b), C.byref(e)), what="ovm_host_shard_range")
+    return b.value, e.value
+
+
+def interp_pos_embed(pos: "np.ndarray", G: int) -> "np.ndarray":
+    """pos [1+M*M, D] float32 -> [1+G*G, D] (host, no GPU needed)."""
+    pos = np.ascontiguousarray(pos, dtype=np.float32)
+    M = int(round((pos.shape[0] - 1) ** 0.5))
+    out = np.empty((1 + G * G, pos.shape[1]), dtype=np.float32)
+    check(load().ovm_host_interp_pos_embed(pos.ctypes.data, M, pos.shape[1], G, out.ctypes.data),
+          what="ovm_host_interp_pos_embed")
+    return out

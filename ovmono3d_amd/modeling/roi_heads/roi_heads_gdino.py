@@ -1,0 +1,59 @@
+"""ROIHeads3DGDINO plugin (reference cubercnn/modeling/roi_heads/roi_heads_gdino.py:26-171).
+
+``forward(..., category_list=None)``: a text-prompted 2D detector supplies the boxes that enter
+``_forward_cube``; as in the reference the RPN/box-head result is not used for the boxes (:118-171)
+and batch size is 1 (:130-134, rcnn3d.py:108-109).
+
+The detector is pluggable: ``self.detector(image_u8_chw, category_list) -> dict(bboxes [n,4] xyxy at
+network resolution, scores [n], labels list[str])``. The reference-owned glue around GroundingDINO
+(caption building :176-181, phrase-logit reduction :273-294, threshold :197, cxcywh->xyxy :266-270,
+NMS :254, class index :162) is in ``ovmono3d_amd.modeling.roi_heads.gdino_glue``; the GroundingDINO
+network itself (Swin-B + BERT + deformable transformer, third-party, not in the reference tree) is the
+next row of the scope table and is NOT implemented in this round - without a detector ``forward``
+raises instead of silently falling back.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional
+
+import torch
+
+from ...registry import ROI_HEADS_REGISTRY
+from ...structures import Boxes, Instances
+from .roi_heads import ROIHeads3D
+
+
+@ROI_HEADS_REGISTRY.register()
+class ROIHeads3DGDINO(ROIHeads3D):
+    def __init__(self, cfg, input_shape=None, priors=None, engine=None, detector: Optional[Callable] = None):
+        super().__init__(cfg, input_shape, priors=priors, engine=engine)
+        self.detector = detector
+
+    def forward(self, images, features, proposals, Ks, im_scales_ratio, targets=None, category_list=None):
+        assert not self.training, "training is out of scope of the native inference path"
+        im_dims = list(images.image_sizes)
+        fuse = bool(getattr(images, "fuse_postprocess", False))
+        if category_list:
+            filtered_texts = [[cat] for cat in category_list]
+        else:
+            # the reference leaves ``filtered_texts`` unbound here (NameError, :130-134)
+            raise NameError("ROIHeads3DGDINO.forward requires category_list (reference roi_heads_gdino.py:130-134)")
+        if len(im_dims) != 1:
+            raise ValueError("GroundingDINO inference supports one image per batch (reference rcnn3d.py:108)")
+        if self.detector is None:
+            raise NotImplementedError(
+                "no text-prompted 2D detector attached: the native GroundingDINO network is not part of this "
+                "round (DESIGN.md, scope row a10). Attach one with roi_heads.detector = callable, or feed "
+                "oracle2D boxes / use MODEL.ROI_HEADS.NAME ROIHeads3D.")
+        det = self.detector(images.raw[0], [t[0] for t in filtered_texts])
+        target = Instances(im_dims[0])
+        class_names = det["labels"]
+        target.pred_classes = torch.tensor([filtered_texts.index([c]) for c in class_names], dtype=torch.int64)  # :162
+        target.pred_boxes = Boxes(torch.as_tensor(det["bboxes"], dtype=torch.float32).reshape(-1, 4))
+        target.scores = torch.as_tensor(det["scores"], dtype=torch.float32)
+        pred = [target]
+        if self.loss_w_3d > 0:
+            pred = self._forward_cube(features, pred, Ks, im_dims, im_scales_ratio, images=images, postprocess=fuse)
+        return pred, {}
+
+    __call__ = forward

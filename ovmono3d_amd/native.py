@@ -1,0 +1,245 @@
+"""Host-side engine: owns one libovm3d handle and moves torch device tensors through the C ABI.
+
+PyTorch is used here only for device memory, the current HIP stream and H2D/D2H copies;
+every arithmetic step of the path runs inside libovm3d's HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .lib import OVM_REC_FLOATS, OvmConfig, OvmImage, check
+from .util.synth_weights import VIT_ARCH
+
+
+def config_to_native(cfg) -> OvmConfig:
+    """Reference config tree -> OvmConfig (keys cited in include/ovm3d.h)."""
+    name = cfg.MODEL.DINO.MODEL_NAME
+    if name not in VIT_ARCH:
+        raise ValueError(f"unsupported MODEL.DINO.MODEL_NAME {name!r} (known: {sorted(VIT_ARCH)})")
+    if cfg.MODEL.DINO.NAME != "dinov2":
+        raise ValueError("only MODEL.DINO.NAME == 'dinov2' is on this path")
+    if cfg.MODEL.DINO.OUTPUT != "dense" or cfg.MODEL.DINO.RETURN_MULTILAYER or cfg.MODEL.DINO.LAYER != -1:
+        raise ValueError("native path supports MODEL.DINO.OUTPUT 'dense', LAYER -1, single layer")
+    H = cfg.MODEL.ROI_CUBE_HEAD
+    unsupported = []
+    if H.Z_TYPE != "direct": unsupported.append("Z_TYPE")
+    if H.POSE_TYPE != "6d": unsupported.append("POSE_TYPE")
+    if H.DIMS_PRIORS_ENABLED: unsupported.append("DIMS_PRIORS_ENABLED")
+    if H.CLUSTER_BINS != 1: unsupported.append("CLUSTER_BINS")
+    if not H.SHARED_FC: unsupported.append("SHARED_FC")
+    if not H.ALLOCENTRIC_POSE: unsupported.append("ALLOCENTRIC_POSE")
+    if not H.VIRTUAL_DEPTH: unsupported.append("VIRTUAL_DEPTH")
+    if not H.USE_CONFIDENCE: unsupported.append("USE_CONFIDENCE")
+    if H.SCALE_ROI_BOXES: unsupported.append("SCALE_ROI_BOXES")
+    if H.NUM_CONV: unsupported.append("NUM_CONV")
+    if unsupported:
+        raise ValueError("ROI_CUBE_HEAD settings outside the OVMono3D-LIFT path (Base.yaml:71-86): " + ", ".join(unsupported))
+    D, L, heads = VIT_ARCH[name]
+    S = int(cfg.MODEL.FPN.SQUARE_PAD)
+    if S <= 0 or S % 14 != 0:
+        raise ValueError("MODEL.FPN.SQUARE_PAD must be a positive multiple of 14")
+    c = OvmConfig()
+    c.embed_dim, c.depth, c.heads = D, L, heads
+    c.pos_grid = 37
+    c.canvas = S
+    c.fpn_channels = int(cfg.MODEL.FPN.OUT_CHANNELS)
+    c.use_depth_fusion = int(bool(cfg.MODEL.DINO.USE_DEPTH_FUSION))
+    for i in range(3):
+        c.pixel_mean[i] = float(cfg.MODEL.PIXEL_MEAN[i])
+        c.pixel_std[i] = float(cfg.MODEL.PIXEL_STD[i])
+    c.num_classes = int(cfg.MODEL.ROI_HEADS.NUM_CLASSES)
+    c.fc_dim = int(H.FC_DIM)
+    c.pooler_res = int(H.POOLER_RESOLUTION)
+    c.pooler_min_level = int(cfg.MODEL.ROI_HEADS.POOLER_MIN_LEVEL)
+    c.pooler_max_level = int(cfg.MODEL.ROI_HEADS.POOLER_MAX_LEVEL)
+    c.virtual_focal = float(H.VIRTUAL_FOCAL)
+    sizes = [s[0] for s in cfg.MODEL.ANCHOR_GENERATOR.SIZES]
+    ratios = list(cfg.MODEL.ANCHOR_GENERATOR.ASPECT_RATIOS[0])
+    if len(sizes) != 3 or len(ratios) != 3:
+        raise ValueError("native RPN expects 3 levels x 3 aspect ratios (OVMono3D_dinov2_SFP.yaml:35-36)")
+    for i in range(3):
+        c.anchor_sizes[i] = float(sizes[i])
+        c.anchor_ratios[i] = float(ratios[i])
+    c.rpn_pre_topk = int(cfg.MODEL.RPN.PRE_NMS_TOPK_TEST)
+    c.rpn_post_topk = int(cfg.MODEL.RPN.POST_NMS_TOPK_TEST)
+    c.rpn_nms_thresh = float(cfg.MODEL.RPN.NMS_THRESH)
+    c.score_thresh = float(cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST)
+    c.nms_thresh = float(cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST)
+    c.detections_per_image = int(cfg.TEST.DETECTIONS_PER_IMAGE)
+    prec = cfg.MODEL.AMD.GEMM_PRECISION
+    if prec not in ("f16", "f16x3"):
+        raise ValueError("MODEL.AMD.GEMM_PRECISION must be 'f16' or 'f16x3'")
+    c.precision = 3 if prec == "f16x3" else 1
+    c.max_batch = int(cfg.MODEL.AMD.MAX_BATCH)
+    c.max_rois = int(cfg.MODEL.AMD.MAX_ROIS)
+    return c
+
+
+class Engine:
+    """One native handle on one device. Not thread-safe (mirrors the reference's 1 thread/process)."""
+
+    def __init__(self, cfg, device: Optional[torch.device] = None):
+        self.cfg = cfg
+        self.ncfg = config_to_native(cfg)
+        self.device = torch.device(device if device is not None else cfg.MODEL.DEVICE)
+        if self.device.type != "cuda":
+            raise RuntimeError("the MI355X-native path runs on a HIP device only (MODEL.DEVICE cuda); "
+                               "there is no CPU fallback")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        self.G = self.ncfg.canvas // 14
+        self.C = self.ncfg.fpn_channels
+
+    # ---- lifecycle ---------------------------------------------------------------------------
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor]) -> None:
+        self.close()
+        sd = {k: v.detach().to("cpu", torch.float32).contiguous().numpy() for k, v in state_dict.items()
+              if isinstance(v, torch.Tensor) and v.dtype.is_floating_point and v.dim() <= 4}
+        table, keep = _lib.make_tensor_table(sd)
+        h = C.c_void_p()
+        torch.cuda.set_device(self.device)
+        rc = self._lib.ovm_create(C.byref(self.ncfg), table, len(keep), self.device.index, C.byref(h))
+        if rc != 0:
+            msg = (self._lib.ovm_last_error(h) or b"").decode() if h else ""
+            if h:
+                self._lib.ovm_destroy(h)
+            raise _lib.OvmError(f"ovm_create failed ({rc}): {msg}")
+        self._h = h
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.ovm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def ready(self) -> bool:
+        return bool(self._h)
+
+    def _require(self):
+        if not self._h:
+            raise RuntimeError("no weights loaded: call model.load_state_dict(...) / DetectionCheckpointer(...).resume_or_load first")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- helpers -----------------------------------------------------------------------------
+    def make_images(self, batched_inputs: Sequence[Dict]) -> Tuple[C.Array, List[torch.Tensor]]:
+        arr = (OvmImage * len(batched_inputs))()
+        keep = []
+        for i, b in enumerate(batched_inputs):
+            im = b["image"]
+            if im.dtype != torch.uint8 or im.dim() != 3:
+                raise TypeError("'image' must be a uint8 tensor [3,H,W] (reference demo.py:83) or [H,W,3]")
+            if im.shape[0] == 3:
+                chw = im
+            elif im.shape[2] == 3:
+                chw = im.permute(2, 0, 1)          # NHWC storage: a stride change, no copy
+            else:
+                raise TypeError("'image' must have 3 channels")
+            chw = chw.to(self.device, non_blocking=True)
+            keep.append(chw)
+            arr[i].data = chw.data_ptr()
+            arr[i].height, arr[i].width = int(chw.shape[1]), int(chw.shape[2])
+            arr[i].stride_c, arr[i].stride_h, arr[i].stride_w = (int(s) for s in chw.stride())
+            arr[i].orig_height = int(b.get("height", chw.shape[1]))
+            arr[i].orig_width = int(b.get("width", chw.shape[2]))
+            K = np.asarray(b["K"], dtype=np.float32).reshape(-1) if "K" in b else np.eye(3, dtype=np.float32).reshape(-1)
+            for j in range(9):
+                arr[i].K[j] = float(K[j])
+        return arr, keep
+
+    # ---- stages ------------------------------------------------------------------------------
+    def backbone_forward(self, images, B: int, prompt_depth: Optional[torch.Tensor] = None, export: bool = False):
+        self._require()
+        dp, dh, dw = None, 0, 0
+        if prompt_depth is not None:
+            prompt_depth = prompt_depth.to(self.device, torch.float32).contiguous()
+            if prompt_depth.dim() == 3:
+                prompt_depth = prompt_depth.unsqueeze(1)
+            dp, dh, dw = prompt_depth.data_ptr(), int(prompt_depth.shape[-2]), int(prompt_depth.shape[-1])
+        outs = [None, None, None]
+        ptrs = [None, None, None]
+        if export:
+            G, Cc = self.G, self.C
+            for i, g in enumerate((2 * G, G, G // 2)):
+                outs[i] = torch.empty((B, g, g, Cc), dtype=torch.float32, device=self.device)
+                ptrs[i] = outs[i].data_ptr()
+        rc = self._lib.ovm_backbone_forward(self._h, images, B, dp, dh, dw, ptrs[0], ptrs[1], ptrs[2], self._stream())
+        check(rc, self._h, "ovm_backbone_forward")
+        if export:
+            # logical NCHW view over NHWC storage (the reference returns NCHW tensors, dino.py:170)
+            return {k: o.permute(0, 3, 1, 2) for k, o in zip(("p2", "p3", "p4"), outs)}
+        return None
+
+    def debug_tensor(self, name: str, numel: int) -> torch.Tensor:
+        self._require()
+        out = torch.empty(numel, dtype=torch.float32, device=self.device)
+        n = self._lib.ovm_debug_copy(self._h, name.encode(), out.data_ptr(), numel, self._stream())
+        if n < 0:
+            check(int(n), self._h, "ovm_debug_copy")
+        return out[:n]
+
+    def cube_forward(self, images, B: int, boxes: torch.Tensor, scores: torch.Tensor, classes: torch.Tensor,
+                     image_idx: torch.Tensor, postprocess: bool = True):
+        """Returns (records [n_keep, 48] float32 device tensor, counts list[int])."""
+        self._require()
+        n = int(boxes.shape[0])
+        dev = self.device
+        boxes = boxes.to(dev, torch.float32).contiguous()
+        scores = scores.to(dev, torch.float32).contiguous()
+        classes = classes.to(dev, torch.int32).contiguous()
+        image_idx = image_idx.to(dev, torch.int32).contiguous()
+        rec = torch.empty((max(n, 1), OVM_REC_FLOATS), dtype=torch.float32, device=dev)
+        counts = torch.zeros(B, dtype=torch.int32, device=dev)
+        rc = self._lib.ovm_cube_forward(self._h, images, B, boxes.data_ptr(), scores.data_ptr(), classes.data_ptr(),
+                                        image_idx.data_ptr(), n, int(bool(postprocess)), rec.data_ptr(),
+                                        counts.data_ptr(), self._stream())
+        check(rc, self._h, "ovm_cube_forward")
+        cl = counts.cpu().tolist()            # one D2H sync per batch (reference: omni3d_evaluation.py:669)
+        return rec[: sum(cl)], cl
+
+    def rpn_box_forward(self, images, B: int):
+        self._require()
+        dev = self.device
+        k = self.ncfg.detections_per_image
+        nc = self.ncfg.num_classes
+        boxes = torch.empty((B * k, 4), dtype=torch.float32, device=dev)
+        scores = torch.empty(B * k, dtype=torch.float32, device=dev)
+        classes = torch.empty(B * k, dtype=torch.int32, device=dev)
+        idx = torch.empty(B * k, dtype=torch.int32, device=dev)
+        full = torch.empty((B * k, nc), dtype=torch.float32, device=dev)
+        counts = torch.zeros(B, dtype=torch.int32, device=dev)
+        rc = self._lib.ovm_rpn_box_forward(self._h, images, B, boxes.data_ptr(), scores.data_ptr(), classes.data_ptr(),
+                                           idx.data_ptr(), full.data_ptr(), counts.data_ptr(), self._stream())
+        check(rc, self._h, "ovm_rpn_box_forward")
+        cl = counts.cpu().tolist()
+        n = sum(cl)
+        return boxes[:n], scores[:n], classes[:n], idx[:n], full[:n], cl
+
+
+def records_to_fields(rec: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Slice [n,48] records into the Instances fields of reference roi_heads.py:823-843 (views)."""
+    n = rec.shape[0]
+    return {
+        "pred_boxes": rec[:, 0:4],
+        "scores": rec[:, 4],
+        "pred_classes": rec[:, 5].contiguous().view(torch.int32).to(torch.int64),
+        "pred_bbox3D": rec[:, 6:30].reshape(n, 8, 3),
+        "pred_center_cam": rec[:, 30:33],
+        "pred_center_2D": rec[:, 33:35],
+        "pred_dimensions": rec[:, 35:38],
+        "pred_pose": rec[:, 38:47].reshape(n, 3, 3),
+    }

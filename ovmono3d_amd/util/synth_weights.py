@@ -1,0 +1,132 @@
+"""Seeded synthetic checkpoints with the reference's state_dict key tree.
+
+There is no network and no checkpoint in the build/test environment, so tests and the bench
+use random-init weights of the exact architecture. Keys follow the module tree printed at
+reference nohup.out:563-684 (``backbone.net.vit.blocks.N...``, ``backbone.simfp_2.0.weight``,
+``roi_heads.cube_head.feature_generator.fc1.weight`` ...), which is what
+``DetectionCheckpointer`` loads at reference demo/demo.py:148.
+
+Value ranges follow SURVEY.md §8d: N(0, 0.02)-like fan-in scaled weights, LN gamma ~ U(0.5,1.5),
+LayerScale gamma ~ U(0.5,1.5)*scale, cube-head output layers std 0.01 so decoded boxes are
+non-degenerate.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+VIT_ARCH = {
+    # name: (embed dim, depth, heads)   -- reference cubercnn/modeling/backbone/dino.py:17-24
+    "vits14": (384, 12, 6),
+    "vitb14": (768, 12, 12),
+    "vitl14": (1024, 24, 16),
+    "vitg14": (1536, 40, 24),
+    # tiny architecture for fast CPU tests (not a hub model)
+    "vittest14": (128, 2, 2),
+}
+
+
+def _lin(g, out_f, in_f, std=None, bias_std=0.02):
+    std = (1.0 / math.sqrt(in_f)) if std is None else std
+    w = torch.randn(out_f, in_f, generator=g) * std
+    b = torch.randn(out_f, generator=g) * bias_std
+    return w, b
+
+
+def synth_state_dict(model_name: str = "vitl14", num_classes: int = 50, fpn_channels: int = 256,
+                     fc_dim: int = 1024, pooler_res: int = 7, seed: int = 0,
+                     depth_fusion: bool = True, pos_grid: int = 37,
+                     num_anchors: int = 3) -> Dict[str, torch.Tensor]:
+    D, L, _ = VIT_ARCH[model_name]
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    V = "backbone.net.vit."
+    sd[V + "cls_token"] = torch.randn(1, 1, D, generator=g) * 0.02
+    sd[V + "pos_embed"] = torch.randn(1, 1 + pos_grid * pos_grid, D, generator=g) * 0.02
+    sd[V + "mask_token"] = torch.zeros(1, D)
+    w = torch.randn(D, 3, 14, 14, generator=g) * (1.0 / math.sqrt(588.0))
+    sd[V + "patch_embed.proj.weight"] = w
+    sd[V + "patch_embed.proj.bias"] = torch.randn(D, generator=g) * 0.02
+    for i in range(L):
+        B = V + f"blocks.{i}."
+        for n in ("norm1", "norm2"):
+            sd[B + n + ".weight"] = 0.5 + torch.rand(D, generator=g)
+            sd[B + n + ".bias"] = torch.randn(D, generator=g) * 0.05
+        sd[B + "attn.qkv.weight"], sd[B + "attn.qkv.bias"] = _lin(g, 3 * D, D, std=2.0 / math.sqrt(D))
+        sd[B + "attn.proj.weight"], sd[B + "attn.proj.bias"] = _lin(g, D, D)
+        sd[B + "ls1.gamma"] = (0.5 + torch.rand(D, generator=g)) * 0.5
+        sd[B + "mlp.fc1.weight"], sd[B + "mlp.fc1.bias"] = _lin(g, 4 * D, D)
+        sd[B + "mlp.fc2.weight"], sd[B + "mlp.fc2.bias"] = _lin(g, D, 4 * D)
+        sd[B + "ls2.gamma"] = (0.5 + torch.rand(D, generator=g)) * 0.5
+    sd[V + "norm.weight"] = torch.ones(D)
+    sd[V + "norm.bias"] = torch.zeros(D)
+    if depth_fusion:
+        w, b = _lin(g, D, D + 1)
+        # keep the fusion close to identity-plus-perturbation so features stay well scaled
+        sd["backbone.net.depth_fusion.weight"] = w.view(D, D + 1, 1, 1).contiguous()
+        sd["backbone.net.depth_fusion.bias"] = b
+
+    C = fpn_channels
+
+    def conv(cout, cin, k, std=None):
+        std = (1.0 / math.sqrt(cin * k * k)) if std is None else std
+        return torch.randn(cout, cin, k, k, generator=g) * std
+
+    def ln(prefix):
+        sd[prefix + ".weight"] = 0.5 + torch.rand(C, generator=g)
+        sd[prefix + ".bias"] = torch.randn(C, generator=g) * 0.05
+
+    # p2: ConvT(D->D/2,k2,s2,bias) -> 1x1(D/2->C)+LN -> 3x3+LN   (nohup.out:565-575)
+    sd["backbone.simfp_2.0.weight"] = torch.randn(D, D // 2, 2, 2, generator=g) * (1.0 / math.sqrt(D))
+    sd["backbone.simfp_2.0.bias"] = torch.randn(D // 2, generator=g) * 0.02
+    sd["backbone.simfp_2.1.weight"] = conv(C, D // 2, 1)
+    ln("backbone.simfp_2.1.norm")
+    sd["backbone.simfp_2.2.weight"] = conv(C, C, 3)
+    ln("backbone.simfp_2.2.norm")
+    # p3: 1x1+LN -> 3x3+LN   (nohup.out:577-585)
+    sd["backbone.simfp_3.0.weight"] = conv(C, D, 1)
+    ln("backbone.simfp_3.0.norm")
+    sd["backbone.simfp_3.1.weight"] = conv(C, C, 3)
+    ln("backbone.simfp_3.1.norm")
+    # p4: MaxPool -> 1x1+LN -> 3x3+LN   (nohup.out:586-596)
+    sd["backbone.simfp_4.1.weight"] = conv(C, D, 1)
+    ln("backbone.simfp_4.1.norm")
+    sd["backbone.simfp_4.2.weight"] = conv(C, C, 3)
+    ln("backbone.simfp_4.2.norm")
+
+    # RPN head (nohup.out:632-639)
+    R = "proposal_generator.rpn_head."
+    sd[R + "conv.weight"] = conv(C, C, 3)
+    sd[R + "conv.bias"] = torch.randn(C, generator=g) * 0.02
+    sd[R + "objectness_logits.weight"] = conv(num_anchors, C, 1, std=0.3)
+    sd[R + "objectness_logits.bias"] = torch.randn(num_anchors, generator=g) * 0.1
+    sd[R + "anchor_deltas.weight"] = conv(4 * num_anchors, C, 1, std=0.02)
+    sd[R + "anchor_deltas.bias"] = torch.randn(4 * num_anchors, generator=g) * 0.02
+
+    # box head + predictor (nohup.out:652-662)
+    K = C * pooler_res * pooler_res
+    H = "roi_heads."
+    sd[H + "box_head.fc1.weight"], sd[H + "box_head.fc1.bias"] = _lin(g, fc_dim, K)
+    sd[H + "box_head.fc2.weight"], sd[H + "box_head.fc2.bias"] = _lin(g, fc_dim, fc_dim)
+    # spread class logits so softmax has a clear winner for a good share of RoIs
+    sd[H + "box_predictor.cls_score.weight"], sd[H + "box_predictor.cls_score.bias"] = \
+        _lin(g, num_classes + 1, fc_dim, std=0.25)
+    sd[H + "box_predictor.bbox_pred.weight"], sd[H + "box_predictor.bbox_pred.bias"] = \
+        _lin(g, num_classes * 4, fc_dim, std=0.02)
+
+    # cube head (nohup.out:663-675; init cube_head.py:109-145, widened so outputs are non-degenerate)
+    Q = H + "cube_head."
+    sd[Q + "feature_generator.fc1.weight"], sd[Q + "feature_generator.fc1.bias"] = _lin(g, fc_dim, K)
+    sd[Q + "feature_generator.fc2.weight"], sd[Q + "feature_generator.fc2.bias"] = _lin(g, fc_dim, fc_dim)
+    for name, nout, bias0 in (("bbox_3D_dims", 3, 0.0), ("bbox_3D_center_deltas", 2, 0.0),
+                              ("bbox_3D_pose", 6, 0.0), ("bbox_3D_center_depth", 1, 2.0),
+                              ("bbox_3D_uncertainty", 1, 0.3)):
+        w = torch.randn(nout, fc_dim, generator=g) * 0.01
+        b = torch.full((nout,), bias0) + torch.randn(nout, generator=g) * 0.01
+        sd[Q + name + ".weight"], sd[Q + name + ".bias"] = w, b
+    # parameters registered by ROIHeads3D.__init__ (roi_heads.py:118-129); unused with priors disabled
+    sd[H + "priors_dims_per_cat"] = torch.ones(1, num_classes, 2, 3)
+    sd[H + "priors_z_scales"] = torch.ones(num_classes, 1)
+    return sd

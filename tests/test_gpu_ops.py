@@ -1,0 +1,214 @@
+"""GPU parity of individual HIP kernels against fp32 torch/oracle references, through the C ABI."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from common import assert_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from ovmono3d_amd import lib
+    return lib.load()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _split(x):
+    L = _lib()
+    hi = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    lo = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    rc = L.ovm_op_split_f16(x.data_ptr(), x.numel(), hi.data_ptr(), lo.data_ptr(), _stream())
+    assert rc == 0
+    return hi, lo
+
+
+def test_split_f16_roundtrip(device):
+    x = torch.randn(10007, device=device) * 3
+    hi, lo = _split(x)
+    rec = hi.float() + lo.float() / 2048.0
+    assert rel_err(rec, x) < 1e-6
+    assert torch.equal(hi, x.half())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 300, 192), (1, 13, 1024), (4097, 384, 128), (77, 1024, 12544)])
+@pytest.mark.parametrize("precision", [1, 3])
+def test_gemm_store(device, M, N, K, precision):
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g).to(device)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(device)
+    bias = torch.randn(N, generator=g).to(device)
+    Npad = (N + 127) // 128 * 128
+    Wp = torch.zeros(Npad, K, device=device)
+    Wp[:N] = W
+    ah, al = _split(A)
+    wh, wl = _split(Wp)
+    Cout = torch.full((M, N + 3), 7.0, device=device)
+    rc = _lib().ovm_op_gemm(ah.data_ptr(), al.data_ptr(), K, wh.data_ptr(), wl.data_ptr(), M, N, K, bias.data_ptr(), 1,
+                            Cout.data_ptr(), N + 3, precision, _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = torch.relu(A.double() @ W.double().T + bias.double()).float()
+    tol = 2e-6 if precision == 3 else 3e-3
+    assert_close(Cout[:, :N], ref, tol, f"gemm {M}x{N}x{K} p{precision}")
+    assert torch.all(Cout[:, N:] == 7.0), "GEMM wrote outside its N range"
+
+
+def test_gemm_exact_integers(device):
+    """A = I-like / asymmetric small integers: catches transposed or permuted fragment maps exactly."""
+    M, N, K = 130, 200, 128
+    A = torch.zeros(M, K, device=device)
+    A[torch.arange(M), torch.arange(M) % K] = 1.0
+    A[:, 5] += 2.0
+    W = (torch.arange(N * K, device=device).reshape(N, K) % 13 - 6).float()
+    Wp = torch.zeros(256, K, device=device); Wp[:N] = W
+    ah, al = _split(A); wh, wl = _split(Wp)
+    for precision in (1, 3):
+        Cout = torch.zeros(M, N, device=device)
+        rc = _lib().ovm_op_gemm(ah.data_ptr(), al.data_ptr(), K, wh.data_ptr(), wl.data_ptr(), M, N, K, None, 0,
+                                Cout.data_ptr(), N, precision, _stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(Cout, A @ W.T)
+
+
+@pytest.mark.parametrize("M,D", [(5, 128), (4097, 1024), (300, 768), (1000, 256), (33, 384)])
+def test_layernorm(device, M, D):
+    x = torch.randn(M, D, device=device) * 2 + 0.5
+    g = torch.rand(D, device=device) + 0.5
+    b = torch.randn(D, device=device)
+    y = torch.empty_like(x)
+    rc = _lib().ovm_op_layernorm(x.data_ptr(), M, D, g.data_ptr(), b.data_ptr(), 1e-6, y.data_ptr(), _stream())
+    assert rc == 0
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), g.double(), b.double(), 1e-6).float()
+    assert_close(y, ref, 2e-6, "layernorm")
+
+
+def _attn_ref(qkv, B, T, heads):
+    D = heads * 64
+    q, k, v = qkv.double().view(B, T, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    a = ((q * 0.125) @ k.transpose(-1, -2)).softmax(-1)
+    return (a @ v).transpose(1, 2).reshape(B * T, D).float()
+
+
+@pytest.mark.parametrize("B,T,heads", [(1, 64, 1), (1, 257, 2), (2, 130, 2), (1, 1370, 2), (1, 4097, 1)])
+@pytest.mark.parametrize("precision", [1, 3])
+def test_attention(device, B, T, heads, precision):
+    g = torch.Generator().manual_seed(T)
+    qkv = (torch.randn(B * T, 3 * heads * 64, generator=g) * 1.5).to(device)
+    out = torch.empty(B * T, heads * 64, device=device)
+    rc = _lib().ovm_op_attention(qkv.data_ptr(), B, T, heads, out.data_ptr(), precision, _stream())
+    assert rc == 0
+    ref = _attn_ref(qkv, B, T, heads)
+    assert_close(out, ref, 5e-6 if precision == 3 else 5e-3, f"attention T={T} p{precision}")
+
+
+def test_attention_max_jump(device):
+    """Forces the online-softmax rescale: one key per query block spikes late in the key sequence."""
+    B, T, heads = 1, 300, 1
+    qkv = torch.randn(B * T, 192, device=device) * 0.3
+    qkv[:, 0:64] = 0.0
+    qkv[:, 0] = 8.0                       # every query looks along dim 0
+    qkv[290, 64] = 40.0                   # key 290 (5th tile) dominates -> running max jumps
+    qkv[10, 64] = 12.0                    # an earlier, smaller spike in tile 0
+    out = torch.empty(B * T, 64, device=device)
+    for precision in (1, 3):
+        rc = _lib().ovm_op_attention(qkv.data_ptr(), B, T, heads, out.data_ptr(), precision, _stream())
+        assert rc == 0
+        assert_close(out, _attn_ref(qkv, B, T, heads), 5e-6 if precision == 3 else 5e-3, "attention max jump")
+
+
+def test_roi_align(device):
+    from oracle.roi_ops import roi_pooler
+    g = torch.Generator().manual_seed(3)
+    Cc, B = 64, 2
+    feats = [torch.randn(B, Cc, s, s, generator=g) for s in (32, 16, 8)]
+    scales = [1 / 7, 1 / 14, 1 / 28]
+    n = 40
+    x1 = torch.rand(n, generator=g) * 150 - 10
+    y1 = torch.rand(n, generator=g) * 150 - 10
+    w = torch.rand(n, generator=g) * 200 + 1
+    h = torch.rand(n, generator=g) * 200 + 1
+    boxes = torch.stack([x1, y1, x1 + w, y1 + h], 1)
+    boxes[0] = torch.tensor([5.0, 5.0, 5.0, 9.0])           # zero width
+    boxes[1] = torch.tensor([-50.0, -50.0, 400.0, 400.0])   # far outside
+    boxes[2] = torch.tensor([10.0, 10.0, 10.5, 10.5])       # sub-pixel
+    idx = torch.cat([torch.zeros(25, dtype=torch.int32), torch.ones(15, dtype=torch.int32)])
+    ref = roi_pooler(feats, [boxes[:25], boxes[25:]], scales, 7, 2, 4)            # [n,C,7,7]
+    ref = ref.permute(0, 2, 3, 1).reshape(n, -1)
+    nhwc = [f.permute(0, 2, 3, 1).contiguous().to(device) for f in feats]
+    hw = (C.c_int32 * 6)(32, 32, 16, 16, 8, 8)
+    sc = (C.c_float * 3)(*scales)
+    out = torch.empty(n, 49 * Cc, device=device)
+    rc = _lib().ovm_op_roi_align(nhwc[0].data_ptr(), nhwc[1].data_ptr(), nhwc[2].data_ptr(), hw, sc, Cc, 7, 2, 4,
+                                 boxes.to(device).data_ptr(), idx.to(device).data_ptr(), n, out.data_ptr(), _stream())
+    assert rc == 0
+    assert_close(out, ref, 2e-6, "roi_align")
+
+
+def test_cube_decode(device):
+    from ovmono3d_amd.lib import OvmImage
+    from oracle import heads as OH
+    g = torch.Generator().manual_seed(5)
+    n = 50
+    head = torch.randn(n, 16, generator=g) * 0.5
+    head[:, 11] = 1.0 + torch.rand(n, generator=g) * 3          # z
+    head[:, 12] = torch.randn(n, generator=g)                   # uncertainty (clip at 0.01 exercised)
+    head[3, 2:5] = 9.0                                          # dims clip at exp(5)
+    x1 = torch.rand(n, generator=g) * 300
+    y1 = torch.rand(n, generator=g) * 200
+    boxes = torch.stack([x1, y1, x1 + 20 + torch.rand(n, generator=g) * 150, y1 + 20 + torch.rand(n, generator=g) * 150], 1)
+    boxes[7] = torch.tensor([600.0, 100.0, 700.0, 150.0])       # outside the image after clipping -> dropped
+    scores = torch.rand(n, generator=g)
+    classes = torch.randint(0, 50, (n,), generator=g, dtype=torch.int32)
+    idx = torch.cat([torch.zeros(30, dtype=torch.int32), torch.ones(20, dtype=torch.int32)])
+    metas = [dict(h=266, w=355, oh=480, ow=640, K=[[900., 0, 320], [0, 900., 240], [0, 0, 1]]),
+             dict(h=532, w=532, oh=512, ow=512, K=[[1024., 0, 256], [0, 1024., 256], [0, 0, 1]])]
+    imgs = (OvmImage * 2)()
+    for i, m in enumerate(metas):
+        imgs[i].height, imgs[i].width, imgs[i].orig_height, imgs[i].orig_width = m["h"], m["w"], m["oh"], m["ow"]
+        for j, v in enumerate(np.asarray(m["K"], dtype=np.float32).reshape(-1)):
+            imgs[i].K[j] = float(v)
+    rec = torch.zeros(n, 48, device=device)
+    keep = torch.zeros(n, dtype=torch.int32, device=device)
+    rc = _lib().ovm_op_cube_decode(head.to(device).data_ptr(), 16, boxes.to(device).data_ptr(), scores.to(device).data_ptr(),
+                                   classes.to(device).data_ptr(), idx.to(device).data_ptr(), imgs, 2, n, 512.0, 1,
+                                   rec.data_ptr(), keep.data_ptr(), _stream())
+    assert rc == 0
+    rec = rec.cpu(); keep = keep.cpu()
+    # oracle: replay forward_cube's decode with the same head outputs
+    nums = [30, 20]
+    Ks = [torch.tensor(m["K"]) for m in metas]
+    ratios = [m["oh"] / m["h"] for m in metas]
+    Ks_box = torch.cat([(Ks[i] / ratios[i]).unsqueeze(0).repeat(k, 1, 1) for i, k in enumerate(nums)])
+    Ks_box[:, -1, -1] = 1
+    focal = torch.cat([Ks[i][1, 1].repeat(k) for i, k in enumerate(nums)])
+    rat = torch.cat([torch.FloatTensor([ratios[i]]).repeat(k) for i, k in enumerate(nums)])
+    ims = torch.cat([torch.FloatTensor([metas[i]["h"]]).repeat(k) for i, k in enumerate(nums)])
+    v2r = OH.compute_virtual_scale_from_focal_spaces(focal, ims * rat, 512.0, ims)
+    sw, sh = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    cx = boxes[:, 0] + 0.5 * sw + sw * head[:, 0]
+    cy = boxes[:, 1] + 0.5 * sh + sh * head[:, 1]
+    dims = torch.exp(head[:, 2:5].clip(max=5))
+    pose = OH.R_from_allocentric(Ks_box, OH.rotation_6d_to_matrix(head[:, 5:11]), cx, cy)
+    z = head[:, 11] * v2r
+    x3 = z * (cx - Ks_box[:, 0, 2]) / Ks_box[:, 0, 0]
+    y3 = z * (cy - Ks_box[:, 1, 2]) / Ks_box[:, 1, 1]
+    conf = torch.exp(-head[:, 12].clip(0.01))
+    verts = OH.get_cuboid_verts(torch.cat([torch.stack([x3, y3, z], 1), dims], 1), pose)
+    tol = 2e-5
+    assert_close(rec[:, 4], (scores * conf).sqrt(), tol, "score")
+    assert_close(rec[:, 6:30].reshape(n, 8, 3), verts, tol, "bbox3D")
+    assert_close(rec[:, 30:33], torch.stack([x3, y3, z], 1), tol, "center_cam")
+    assert_close(rec[:, 33:35], torch.stack([cx, cy], 1) * rat[:, None], tol, "center_2D")
+    assert_close(rec[:, 35:38], dims, tol, "dims")
+    assert_close(rec[:, 38:47].reshape(n, 3, 3), pose, tol, "pose")
+    assert torch.equal(rec[:, 5].contiguous().view(torch.int32), classes)
+    assert torch.equal(rec[:, 47].contiguous().view(torch.int32), idx)
+    assert keep[7] == 0 and keep.sum() == n - 1
