@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X-native OVMono3D-LIFT inference path.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" = one pass of the hot path (preprocess -> DINOv2 ViT + SFP -> ROIAlign -> cube head -> decode
+-> postprocess -> per-image detection counts back on the host) over one batch of synthetic images that
+are already resident in HBM. Workload = BASELINE.json configs[1]: DINOv2-L/14 + SFP, batch 1, a
+512x512x3 synthetic image at network resolution 532x532 (ResizeShortestEdge(532) is host data feeding,
+outside the path) on the reference's 896x896 SQUARE_PAD canvas (T = 4097 tokens). The 2D boxes come from
+the oracle-2D branch (32 boxes/image, SURVEY.md §8d mode A): the native GroundingDINO network that
+ROIHeads3DGDINO would call is not built yet.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP
+events on the launch stream) and `cpu_baseline` (the fp32 torch CPU oracle on the host cores, rank 0,
+N=1 only, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+PEAK_F16_TFLOPS = 2516.6        # 256 CU x 2.4 GHz x 4096 FLOP/clk/CU, dense (MI355X_MICROARCH.md)
+
+
+def vit_flops(T, D, L, G2):
+    per_layer = 24.0 * T * D * D + 4.0 * T * T * D
+    return L * per_layer + 2.0 * G2 * 588 * D
+
+
+def kernel_flops(T, D):
+    """Algorithmic FLOPs per launch (batch 1) of each profiled kernel category."""
+    return {"attn": 4.0 * T * T * D, "qkv": 6.0 * T * D * D, "proj": 2.0 * T * D * D,
+            "fc1": 8.0 * T * D * D, "fc2": 8.0 * T * D * D}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16"])
+    ap.add_argument("--model", default="vitl14")
+    ap.add_argument("--canvas", type=int, default=896)
+    ap.add_argument("--net-res", type=int, default=532)
+    ap.add_argument("--boxes", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra one-pass fp16 measurement")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from common import build_cfg, oracle_params
+    from ovmono3d_amd.modeling import build_model
+    from ovmono3d_amd.util.synth_weights import VIT_ARCH, synth_state_dict
+
+    D, L, heads = VIT_ARCH[args.model]
+    G = args.canvas // 14
+    T = G * G + 1
+    B = args.batch
+
+    def make_inputs(seed):
+        g = torch.Generator().manual_seed(seed)
+        out = []
+        for i in range(B):
+            img = torch.randint(0, 256, (3, args.net_res, args.net_res), dtype=torch.uint8, generator=g)
+            oh = ow = 512
+            K = [[1024.0, 0.0, 256.0], [0.0, 1024.0, 256.0], [0.0, 0.0, 1.0]]      # demo.py:63-76 focal 4.0*h/2
+            x1 = torch.rand(args.boxes, generator=g) * 384
+            y1 = torch.rand(args.boxes, generator=g) * 384
+            w = 32 + torch.rand(args.boxes, generator=g) * 96
+            h = 32 + torch.rand(args.boxes, generator=g) * 96
+            boxes = torch.stack([x1, y1, x1 + w, y1 + h], 1)
+            out.append({"image": img, "height": oh, "width": ow, "K": K, "image_id": i,
+                        "oracle2D": {"gt_bbox2D": boxes, "gt_classes": torch.randint(0, 50, (args.boxes,), generator=g),
+                                     "gt_scores": 0.3 + 0.7 * torch.rand(args.boxes, generator=g)}})
+        return out
+
+    sd = synth_state_dict(args.model, seed=0)
+
+    def run(precision, steps, warmup, profile):
+        cfg = build_cfg(args.model, args.canvas, precision, max_batch=B, max_rois=max(64, args.boxes))
+        model = build_model(cfg, device=dev)
+        model.load_state_dict(sd)
+        host_inputs = make_inputs(1000 + rank)
+        inputs = []
+        for d in host_inputs:                      # images resident in HBM before the timed region
+            d = dict(d)
+            d["image"] = d["image"].to(dev)
+            inputs.append(d)
+        ndet = 0
+        for _ in range(warmup):
+            out = model(inputs)
+        torch.cuda.synchronize()
+        if profile:
+            model.engine.profile_enable(True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = model(inputs)
+            ndet += sum(len(o["instances"]) for o in out)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        prof = model.engine.profile_read() if profile else None
+        if profile:
+            model.engine.profile_enable(False)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, prof, ndet, model, host_inputs, cfg
+
+    dt, prof, ndet, model, host_inputs, cfg = run(args.precision, args.steps, args.warmup, True)
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    # ---- roofline of the dominant kernel (HIP events, launch stream) ----
+    kf = kernel_flops(T, D)
+    dominant = max((k for k in kf), key=lambda k: prof[k][0])
+    tot_ms, launches = prof[dominant]
+    avg_ms = tot_ms / max(launches, 1)
+    flops_launch = kf[dominant] * B
+    achieved = flops_launch / (avg_ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+                "algorithmic_flops_per_launch": flops_launch,
+                "mfma_passes_per_product": 3 if args.precision == "f16x3" else 1}
+    kernels = {k: {"ms_per_step": round(prof[k][0] / args.steps, 4), "launches_per_step": prof[k][1] // args.steps,
+                   **({"tflops": round(kf[k] * B * prof[k][1] / (prof[k][0] * 1e-3) / 1e12, 2)} if k in kf and prof[k][0] > 0 else {})}
+               for k in prof}
+    total_flops = vit_flops(T, D, L, G * G) * B
+    e2e_tflops = total_flops * args.steps / dt / 1e12
+
+    alt = None
+    if not args.no_alt and args.precision == "f16x3" and world == 1:
+        del model
+        torch.cuda.empty_cache()
+        dt2, prof2, _, model2, _, _ = run("f16", args.steps, args.warmup, True)
+        d2 = max((k for k in kf), key=lambda k: prof2[k][0])
+        alt = {"precision": "f16 (one MFMA pass; outside the 1e-3 parity band on the synthetic checkpoint)",
+               "value": round(B * args.steps / dt2, 3), "ms_per_step": round(dt2 / args.steps * 1e3, 3),
+               "dominant_kernel": d2,
+               "dominant_tflops": round(kf[d2] * B * prof2[d2][1] / (prof2[d2][0] * 1e-3) / 1e12, 2)}
+        del model2
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.pipeline import inference
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        # the GPU box gives a 1-GPU job a 16-core share; more torch threads than that only oversubscribe
+        ncores = int(os.environ.get("OVM_CPU_THREADS", min(avail, 16)))
+        torch.set_num_threads(ncores)
+        P = oracle_params(cfg)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            nimg = 0
+            while True:
+                inference(sd, host_inputs[:1], P)
+                nimg += 1
+                el = time.perf_counter() - t0
+                if el > 12.0 or nimg >= 3:
+                    break
+        cpu_baseline = {"value": round(nimg / el, 4), "unit": "images/sec", "cores": ncores, "kind": "port",
+                        "sample": f"{nimg} image(s) of the same workload through oracle/ (fp32 torch CPU restatement), "
+                                  f"{el:.1f} s, torch threads={ncores}"}
+
+    if rank == 0:
+        line = {
+            "metric": "images/sec/GPU @512x512 DINOv2-L SFP; AP3D delta vs reference",
+            "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16x3" if args.precision == "f16x3" else "f16", "data": "synthetic",
+            "config": {"workload": f"DINOv2 {args.model} + SFP + oracle-2D boxes ({args.boxes}/img) + ROIAlign + CubeHead + decode, "
+                                   f"batch {B}/GPU, 512x512 synthetic -> network res {args.net_res} -> canvas {args.canvas} (T={T}), "
+                                   f"random-init weights (seed 0)",
+                       "proposal_source": "oracle2D (native GroundingDINO for ROIHeads3DGDINO not built yet)",
+                       "precision": args.precision, "parallelism": f"dp{world} (image-sharded, no data-path collective)",
+                       "ap3d_delta": "not measurable offline (no Omni3D data / checkpoint); tensor parity vs CPU oracle <=1e-3"},
+            "images_per_sec_per_gpu": round(value / world, 3),
+            "vit_tflops_end_to_end": round(e2e_tflops, 2),
+            "detections_per_step": ndet // max(args.steps, 1),
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu_baseline,
+        }
+        if alt:
+            line["alt_precision"] = alt
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

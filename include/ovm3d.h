@@ -138,6 +138,22 @@ int ovm_rpn_box_forward(OvmHandle* h, const OvmImage* images, int32_t B, float* 
 int ovm_gather_records(void* comm, int32_t rank, int32_t world, const OvmDet3D* send, int32_t n_send,
                        OvmDet3D* recv, int32_t* counts_all, ovm_stream_t stream);
 
+int ovm_comm_unique_id(uint8_t* id128);                                     /* ncclGetUniqueId */
+int ovm_comm_init(const uint8_t* id128, int32_t rank, int32_t world, int32_t device, void** comm);
+int ovm_comm_destroy(void* comm);
+
+/* --- per-kernel timing with HIP events recorded on the stream the kernels are launched on (what
+ * bench.py's roofline figure is computed from). Categories index the ms/launches arrays. */
+#define OVM_PROF_ATTN 0
+#define OVM_PROF_QKV 1
+#define OVM_PROF_PROJ 2
+#define OVM_PROF_FC1 3
+#define OVM_PROF_FC2 4
+#define OVM_PROF_LN 5
+#define OVM_PROF_NCAT 6
+int ovm_profile_enable(OvmHandle* h, int32_t on);
+int ovm_profile_read(OvmHandle* h, float* ms /* [OVM_PROF_NCAT] */, int32_t* launches /* [OVM_PROF_NCAT] */);
+
 /* --- host-side helpers (no GPU needed) -------------------------------------------------------- */
 /* dinov2 interpolate_pos_encoding (hub: offset 0.1, bicubic, no antialias): pos [1+M*M][D] -> out [1+G*G][D] */
 int ovm_host_interp_pos_embed(const float* pos, int32_t M, int32_t D, int32_t G, float* out);

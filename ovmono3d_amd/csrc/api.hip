@@ -66,6 +66,10 @@ struct OvmHandle {
   ImageDesc* h_imgs = nullptr; ImageMeta* h_meta = nullptr;     // pinned staging
   Det2dWorkspace det;
   int lastB = 0;
+  // optional per-kernel-category timing with HIP events on the caller's stream
+  bool prof = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[OVM_PROF_NCAT];
+  size_t prof_used[OVM_PROF_NCAT] = {0};
 };
 
 namespace {
@@ -239,7 +243,25 @@ int pack_sfp_stage(OvmHandle* h, const WeightMap& wm, const std::string& p1, con
   return upload_f32(h, wm, p3 + ".norm.bias", C, &s->n3b);
 }
 
-int gemm(OvmHandle* h, const GemmParams& p, int epi, int amode, hipStream_t s) {
+struct ProfScope {
+  OvmHandle* h; int cat; hipStream_t s; hipEvent_t stop = nullptr;
+  ProfScope(OvmHandle* h_, int cat_, hipStream_t s_) : h(h_), cat(cat_), s(s_) {
+    if (!h->prof || cat < 0) return;
+    auto& pool = h->prof_ev[cat];
+    if (h->prof_used[cat] == pool.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      pool.push_back({a, b});
+    }
+    auto& pr = pool[h->prof_used[cat]++];
+    (void)hipEventRecord(pr.first, s);
+    stop = pr.second;
+  }
+  ~ProfScope() { if (stop) (void)hipEventRecord(stop, s); }
+};
+
+int gemm(OvmHandle* h, const GemmParams& p, int epi, int amode, hipStream_t s, int cat = -1) {
+  ProfScope ps(h, cat, s);
   return launch_gemm(p, h->npass, epi, amode, s);
 }
 
@@ -277,6 +299,8 @@ int ovm_destroy(OvmHandle* h) {
   for (void* p : h->allocs) hipFree(p);
   if (h->h_imgs) hipHostFree(h->h_imgs);
   if (h->h_meta) hipHostFree(h->h_meta);
+  for (int c = 0; c < OVM_PROF_NCAT; ++c)
+    for (auto& pr : h->prof_ev[c]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   delete h;
   return OVM_OK;
 }
@@ -531,34 +555,34 @@ int ovm_backbone_forward(OvmHandle* h, const OvmImage* images, int32_t B, const 
   for (int l = 0; l < L; ++l) {
     const Layer& y = h->layers[l];
     LnOut o; memset(&o, 0, sizeof(o)); o.hi = h->HN.hi; o.lo = h->HN.lo; o.ld = D;
-    KCHECK(h, launch_ln_rows(h->X, D, M, D, y.ln1g, y.ln1b, 1e-6f, o, s));
+    { ProfScope ps(h, OVM_PROF_LN, s); KCHECK(h, launch_ln_rows(h->X, D, M, D, y.ln1g, y.ln1b, 1e-6f, o, s)); }
     {
       GemmParams p = gp_base(h->HN, D, y.qkv, M);
       p.Qhi = h->Q.hi; p.Qlo = h->Q.lo; p.Khi = h->Kx.hi; p.Klo = h->Kx.lo; p.Vhi = h->Vt.hi; p.Vlo = h->Vt.lo;
       p.T = T; p.Tpad = h->Tpad; p.heads = c.heads; p.qscale = 0.125f;
-      KCHECK(h, gemm(h, p, EPI_QKV, A_ROWMAJOR, s));
+      KCHECK(h, gemm(h, p, EPI_QKV, A_ROWMAJOR, s, OVM_PROF_QKV));
     }
     {
       AttnParams a; memset(&a, 0, sizeof(a));
       a.Qhi = h->Q.hi; a.Qlo = h->Q.lo; a.Khi = h->Kx.hi; a.Klo = h->Kx.lo; a.Vhi = h->Vt.hi; a.Vlo = h->Vt.lo;
       a.Ohi = h->AO.hi; a.Olo = h->AO.lo; a.ldo = D; a.B = B; a.heads = c.heads; a.T = T; a.Tpad = h->Tpad;
-      KCHECK(h, launch_attention(a, h->npass, s));
+      { ProfScope ps(h, OVM_PROF_ATTN, s); KCHECK(h, launch_attention(a, h->npass, s)); }
     }
     {
       GemmParams p = gp_base(h->AO, D, y.proj, M);
       p.gamma = y.ls1; p.X = h->X; p.ldx = D;
-      KCHECK(h, gemm(h, p, EPI_RESID, A_ROWMAJOR, s));
+      KCHECK(h, gemm(h, p, EPI_RESID, A_ROWMAJOR, s, OVM_PROF_PROJ));
     }
-    KCHECK(h, launch_ln_rows(h->X, D, M, D, y.ln2g, y.ln2b, 1e-6f, o, s));
+    { ProfScope ps(h, OVM_PROF_LN, s); KCHECK(h, launch_ln_rows(h->X, D, M, D, y.ln2g, y.ln2b, 1e-6f, o, s)); }
     {
       GemmParams p = gp_base(h->HN, D, y.fc1, M);
       p.Ohi = h->F1.hi; p.Olo = h->F1.lo; p.ldo = 4 * D;
-      KCHECK(h, gemm(h, p, EPI_GELU, A_ROWMAJOR, s));
+      KCHECK(h, gemm(h, p, EPI_GELU, A_ROWMAJOR, s, OVM_PROF_FC1));
     }
     {
       GemmParams p = gp_base(h->F1, 4 * D, y.fc2, M);
       p.gamma = y.ls2; p.X = h->X; p.ldx = D;
-      KCHECK(h, gemm(h, p, EPI_RESID, A_ROWMAJOR, s));
+      KCHECK(h, gemm(h, p, EPI_RESID, A_ROWMAJOR, s, OVM_PROF_FC2));
     }
   }
   // ---- depth fusion at the last block output (reference dino.py:91-105) ----
@@ -671,6 +695,53 @@ int ovm_rpn_box_forward(OvmHandle* h, const OvmImage* images, int32_t B, float* 
   m.roi = rp; m.RF = {h->RF.hi, h->RF.lo}; m.H1 = {h->H1.hi, h->H1.lo}; m.H2 = {h->H2.hi, h->H2.lo}; m.HO = h->HO;
   int r = det2d_forward(m, h->det, boxes, scores, classes, image_idx, scores_full, out_counts, s);
   if (r) { h->err = "det2d_forward failed (" + std::to_string(r) + ")"; return r; }
+  return OVM_OK;
+}
+
+int ovm_profile_enable(OvmHandle* h, int32_t on) {
+  if (!h) return OVM_ERR_INVALID;
+  h->prof = on != 0;
+  for (int c = 0; c < OVM_PROF_NCAT; ++c) h->prof_used[c] = 0;
+  return OVM_OK;
+}
+
+// Sums the elapsed time of every bracketed launch since ovm_profile_enable(h, 1) per category and
+// resets the counters. Synchronises the device.
+int ovm_profile_read(OvmHandle* h, float* ms, int32_t* launches) {
+  if (!h) return OVM_ERR_INVALID;
+  HCHECK(h, hipSetDevice(h->device));
+  HCHECK(h, hipDeviceSynchronize());
+  for (int c = 0; c < OVM_PROF_NCAT; ++c) {
+    double tot = 0.0;
+    for (size_t i = 0; i < h->prof_used[c]; ++i) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, h->prof_ev[c][i].first, h->prof_ev[c][i].second) == hipSuccess) tot += t;
+    }
+    ms[c] = (float)tot; launches[c] = (int32_t)h->prof_used[c];
+    h->prof_used[c] = 0;
+  }
+  return OVM_OK;
+}
+
+// RCCL communicator bootstrap for ovm_gather_records (the unique id travels over the host's own
+// rendezvous, e.g. torch.distributed's store).
+int ovm_comm_unique_id(uint8_t* id128) {
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return OVM_ERR_HIP;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+  memcpy(id128, &id, 128);
+  return OVM_OK;
+}
+int ovm_comm_init(const uint8_t* id128, int32_t rank, int32_t world, int32_t device, void** comm) {
+  ncclUniqueId id; memcpy(&id, id128, 128);
+  if (hipSetDevice(device) != hipSuccess) return OVM_ERR_HIP;
+  ncclComm_t c;
+  if (ncclCommInitRank(&c, world, id, rank) != ncclSuccess) return OVM_ERR_HIP;
+  *comm = (void*)c;
+  return OVM_OK;
+}
+int ovm_comm_destroy(void* comm) {
+  if (comm) ncclCommDestroy((ncclComm_t)comm);
   return OVM_OK;
 }
 

@@ -48,8 +48,10 @@ EXPORTS = [
     "ovm_create", "ovm_destroy", "ovm_last_error", "ovm_version", "ovm_backbone_forward", "ovm_cube_forward",
     "ovm_rpn_box_forward", "ovm_gather_records", "ovm_host_interp_pos_embed", "ovm_host_shard_range",
     "ovm_op_split_f16", "ovm_op_gemm", "ovm_op_layernorm", "ovm_op_attention", "ovm_op_roi_align",
-    "ovm_op_cube_decode", "ovm_op_nms", "ovm_debug_copy",
+    "ovm_op_cube_decode", "ovm_op_nms", "ovm_debug_copy", "ovm_profile_enable", "ovm_profile_read",
+    "ovm_comm_unique_id", "ovm_comm_init", "ovm_comm_destroy",
 ]
+PROF_NAMES = ("attn", "qkv", "proj", "fc1", "fc2", "ln")
 
 _lib = None
 
@@ -85,6 +87,11 @@ def load() -> C.CDLL:
     lib.ovm_op_nms.argtypes = [vp, vp, i32, f32, vp, vp, vp]
     lib.ovm_debug_copy.argtypes = [vp, C.c_char_p, vp, i64, vp]
     lib.ovm_debug_copy.restype = i64
+    lib.ovm_profile_enable.argtypes = [vp, i32]
+    lib.ovm_profile_read.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]
+    lib.ovm_comm_unique_id.argtypes = [vp]
+    lib.ovm_comm_init.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    lib.ovm_comm_destroy.argtypes = [vp]
     for name in EXPORTS:
         if name not in ("ovm_last_error", "ovm_version", "ovm_debug_copy"):
             getattr(lib, name).restype = i32

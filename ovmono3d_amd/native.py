@@ -211,6 +211,18 @@ class Engine:
         cl = counts.cpu().tolist()            # one D2H sync per batch (reference: omni3d_evaluation.py:669)
         return rec[: sum(cl)], cl
 
+    def profile_enable(self, on: bool = True) -> None:
+        self._require()
+        check(self._lib.ovm_profile_enable(self._h, int(on)), self._h, "ovm_profile_enable")
+
+    def profile_read(self) -> Dict[str, Tuple[float, int]]:
+        """{category: (total ms, launches)} since profile_enable(True); synchronises the device."""
+        self._require()
+        ms = (C.c_float * len(_lib.PROF_NAMES))()
+        cnt = (C.c_int32 * len(_lib.PROF_NAMES))()
+        check(self._lib.ovm_profile_read(self._h, ms, cnt), self._h, "ovm_profile_read")
+        return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(_lib.PROF_NAMES)}
+
     def rpn_box_forward(self, images, B: int):
         self._require()
         dev = self.device

@@ -80,3 +80,32 @@ def assert_close(a, b, tol, name=""):
     e = rel_err(a, b)
     assert e <= tol, f"{name}: scale-relative error {e:.3e} > {tol:.1e}"
     return e
+
+
+# ------------------------------------------------------------------------------------------ golden
+def load_golden(name):
+    """Returns (inputs, expected per-image dicts, raw npz) for a fixture written by tests/golden/make_golden.py."""
+    z = np.load(os.path.join(GOLDEN, name))
+    n = int(z["n_images"])
+    inputs, expected = [], []
+    for i in range(n):
+        h, w = (int(v) for v in z[f"in_meta{i}"])
+        d = {"image": torch.from_numpy(z[f"in_img{i}"]), "height": h, "width": w, "K": z[f"in_K{i}"].tolist(), "image_id": i}
+        if f"in_box{i}" in z:
+            d["oracle2D"] = {"gt_bbox2D": torch.from_numpy(z[f"in_box{i}"]), "gt_classes": torch.from_numpy(z[f"in_cls{i}"]),
+                             "gt_scores": torch.from_numpy(z[f"in_sc{i}"])}
+        if f"in_depth{i}" in z:
+            d["depth"] = torch.from_numpy(z[f"in_depth{i}"])
+        inputs.append(d)
+        expected.append({k[len(f"out{i}_"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"out{i}_")})
+    return inputs, expected, z
+
+
+def golden_weights(z):
+    """Re-creates the fixture's synthetic checkpoint and verifies its fingerprint (guards against a
+    change of torch's CPU RNG stream, which would invalidate the stored outputs)."""
+    sd = synth_state_dict("vittest14", seed=int(z["weights_seed"]))
+    keys = sorted(sd)[:: max(1, len(sd) // 16)]
+    fp = np.array([float(sd[k].double().sum()) for k in keys])
+    ok = np.allclose(fp, z["weights_fp"], rtol=1e-9, atol=1e-9)
+    return sd, ok

@@ -1,0 +1,64 @@
+"""The C-ABI library loads and exports every symbol include/ovm3d.h declares (no GPU compute calls)."""
+import ctypes as C
+import os
+import re
+
+from common import ROOT
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "ovm3d.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ovm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_exports_every_declared_symbol():
+    from ovmono3d_amd import lib
+    L = lib.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), f"libovm3d.so does not export {n}"
+    assert sorted(lib.EXPORTS) == names, "lib.EXPORTS out of sync with include/ovm3d.h"
+
+
+def test_struct_layouts_match_header():
+    from ovmono3d_amd import lib
+    # OvmDet3D is 48 x 4 bytes; OvmImage / OvmTensor as declared
+    assert lib.OVM_REC_FLOATS * 4 == 192
+    assert C.sizeof(lib.OvmImage) == 8 + 4 + 4 + 8 * 3 + 4 + 4 + 36 + 4          # trailing pad to 8
+    assert C.sizeof(lib.OvmTensor) == 8 + 8 + 8 + 32
+    assert C.sizeof(lib.OvmConfig) == 4 * 7 + 12 + 12 + 4 * 5 + 4 + 12 + 12 + 4 * 2 + 4 + 4 + 4 + 4 + 4 * 3
+
+
+def test_version_and_error_strings():
+    from ovmono3d_amd import lib
+    L = lib.load()
+    assert b"libovm3d" in L.ovm_version()
+    assert L.ovm_last_error(None) == b"null handle"
+
+
+def test_create_rejects_bad_config_without_gpu_work():
+    """Argument validation happens before any device call."""
+    from ovmono3d_amd import lib
+    L = lib.load()
+    cfg = lib.OvmConfig()
+    cfg.embed_dim, cfg.depth, cfg.heads, cfg.canvas = 100, 1, 1, 225     # canvas not a multiple of 14
+    cfg.precision, cfg.max_batch, cfg.max_rois, cfg.fpn_channels = 1, 1, 1, 256
+    h = C.c_void_p()
+    rc = L.ovm_create(C.byref(cfg), None, 0, 0, C.byref(h))
+    assert rc == -1
+    assert b"invalid config" in L.ovm_last_error(h)
+    L.ovm_destroy(h)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from ovmono3d_amd import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    try:
+        lib.load()
+    except RuntimeError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("load() must raise when the shared object is absent")
