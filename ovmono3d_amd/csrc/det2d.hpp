@@ -1,4 +1,9 @@
 // RPN inference + 2D box head + Fast R-CNN inference (mode "B" of the path), device side.
+//
+// Discrete steps (top-k, per-level / per-class NMS, final top-k) are done with one generic primitive,
+// a batched bitonic sort of 64-bit composite keys in HBM/LDS, plus a bit-matrix NMS. Keys carry
+// (group | inverted order-preserving score bits | candidate id), so ordering - including ties - is
+// deterministic: higher score first, lower index first on exact ties.
 #pragma once
 #include <vector>
 #include "kernels.hpp"
@@ -8,24 +13,25 @@ namespace ovm {
 struct SplitPtr { half_t* hi; half_t* lo; };
 
 struct Det2dWorkspace {
-  // RPN
-  SplitPtr rpn_t[3];        // conv3x3+ReLU output per level, fp16 split [B*H*W][C]
-  float* rpn_o[3];          // [B*H*W][16] fp32: 3 objectness logits + 12 deltas
-  float* lvl_scores;        // [B][3][pre_topk]
-  float* lvl_boxes;         // [B][3][pre_topk][4]
-  int* lvl_count;           // [B][3]
-  float* prop_boxes;        // [B][post_topk][4]
-  float* prop_scores;       // [B][post_topk]
-  int* prop_bidx;           // [B][post_topk]
-  int* prop_count;          // [B]
-  unsigned long long* nms_mask;   // scratch bit matrix
-  unsigned int* hist;       // radix-select scratch
-  int* sel_idx; float* sel_key;    // candidate buffers
-  int* sort_idx; float* sort_key;
+  int maxB, G, C, num_classes, R, pre_topk, topk;
+  int HW[3], Wl[3];                    // per level pixels / width
+  int A_tot;                           // total anchors per image
+  int Nrpn;                            // pow2 >= A_tot (sort length)
+  int Ncand;                           // pow2 >= R * num_classes
+  int Nmerge;                          // pow2 >= 3 * pre_topk
+  SplitPtr rpn_t[3];                   // conv3x3+ReLU output per level, fp16 split [B*HW][C]
+  float* rpn_o[3];                     // [B*HW][16] fp32: 3 objectness logits + 12 deltas
+  unsigned long long* keys;            // [B][max(Nrpn, Ncand)]
+  // RPN candidates, slot = l*pre_topk + i
+  float* cbox; float* cscore; int* cgroup; int* cseg; int* ckeep;     // [B][3*pre_topk](x4)
+  int* gstart; int* gend;              // [B][max(3, num_classes)]
+  unsigned long long* mask;            // [B][Nmask][16]
+  unsigned long long* mkeys;           // [B][Nmerge]
+  float* prop_boxes; float* prop_scores; int* prop_bidx; int* prop_count;   // [B][R]
   // box head
-  float* cand_boxes; float* cand_scores; int* cand_cls; int* cand_row; int* cand_count;
-  int* keep_flags;
-  int maxB, maxR, pre_topk, post_topk, topk, num_classes, cand_cap;
+  float* probs;                        // [B*R][64]
+  float* dbox;                         // [B*R][num_classes][4] decoded + clipped
+  float* sbox; int* sgroup; int* sseg; int* skeep;                    // [B][Ncand] gathered by sorted position
 };
 
 struct Det2dModel {
@@ -48,6 +54,7 @@ int det2d_alloc(Det2dWorkspace* w, int B, int G, int C, int num_classes, int max
                 std::vector<void*>* allocs);
 int det2d_forward(const Det2dModel& m, Det2dWorkspace& w, float* boxes, float* scores, int* classes, int* image_idx,
                   float* scores_full, int* out_counts, hipStream_t s);
+// Standalone class-agnostic NMS (torchvision.ops.nms semantics): keep_idx in decreasing-score order.
 int launch_nms_single(const float* boxes, const float* scores, int n, float thresh, int* keep_idx, int* n_keep, hipStream_t s);
 
 }  // namespace ovm

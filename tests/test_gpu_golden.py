@@ -22,7 +22,7 @@ def _run(name, device):
     return out, expected, z, model, inputs
 
 
-@pytest.mark.parametrize("name", ["e2e_oracle2d_vittest14.npz", "e2e_depth_vittest14.npz"])
+@pytest.mark.parametrize("name", ["e2e_oracle2d_vittest14.npz", "e2e_depth_vittest14.npz", "e2e_rpn_vittest14.npz"])
 def test_native_matches_golden(device, name):
     out, expected, z, model, inputs = _run(name, device)
     for o, e in zip(out, expected):

@@ -100,3 +100,16 @@ def test_empty_and_degenerate_boxes(device):
     inputs[0]["oracle2D"]["gt_bbox2D"][1] = torch.tensor([10.0, 10.0, 10.0, 40.0])   # empty after postprocess
     out = model(inputs)
     assert len(out[0]["instances"]) == 3
+
+
+def test_rpn_boxhead_path_tiny_vit(device):
+    """No oracle boxes -> RPN -> box head -> Fast R-CNN inference -> cube head (reference rcnn3d.py:105-111)."""
+    from oracle.pipeline import inference
+    cfg = build_cfg("vittest14", 224, "f16x3", max_batch=2)
+    model, sd = _build(cfg, seed=21)
+    inputs = synth_inputs(2, hw=((168, 210), (224, 224)), n_boxes=0, seed=24, oracle2d=False)
+    out = model(inputs)
+    ref = inference(sd, inputs, oracle_params(cfg))
+    assert len(out[0]["instances"]) > 0
+    _compare(out, ref)
+    assert out[0]["instances"].has("pred_bbox3D")

@@ -213,3 +213,21 @@ def test_cube_decode(device):
     assert torch.equal(rec[:, 5].contiguous().view(torch.int32), classes)
     assert torch.equal(rec[:, 47].contiguous().view(torch.int32), idx)
     assert keep[7] == 0 and keep.sum() == n - 1
+
+
+@pytest.mark.parametrize("n", [1, 7, 300, 900, 2500])
+def test_nms_op(device, n):
+    from oracle.roi_ops import nms
+    g = torch.Generator().manual_seed(n)
+    xy = torch.rand(n, 2, generator=g) * 300
+    wh = torch.rand(n, 2, generator=g) * 120 + 2
+    boxes = torch.cat([xy, xy + wh], 1)
+    scores = torch.rand(n, generator=g)
+    ref = nms(boxes, scores, 0.5)
+    db, ds = boxes.to(device), scores.to(device)
+    keep = torch.full((n,), -1, dtype=torch.int32, device=device)
+    nk = torch.zeros(1, dtype=torch.int32, device=device)
+    rc = _lib().ovm_op_nms(db.data_ptr(), ds.data_ptr(), n, 0.5, keep.data_ptr(), nk.data_ptr(), _stream())
+    assert rc == 0
+    k = int(nk.item())
+    assert keep[:k].cpu().tolist() == ref.tolist()
