@@ -1,0 +1,132 @@
+"""Host-side entry-point plumbing that needs no GPU: data feeding, record <-> JSON, the per-rank loop with a stub model,
+and the 2-rank gloo run of inference_on_dataset (dataset order preserved through shards + gather)."""
+import json
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from common import build_cfg
+from ovmono3d_amd.structures import Boxes, Instances
+
+
+def test_resize_shortest_edge_matches_reference_examples():
+    """500x500 -> 532x532, 480x640 -> 532x709 under ResizeShortestEdge(532, 896)."""
+    from ovmono3d_amd.data import ResizeShortestEdge
+    r = ResizeShortestEdge(532, 896)
+    assert r.output_shape(500, 500) == (532, 532)
+    assert r.output_shape(480, 640) == (532, 709)
+    assert r.output_shape(300, 1200) == (224, 896)
+    img = np.random.default_rng(0).integers(0, 255, (120, 160, 3), dtype=np.uint8)
+    assert ResizeShortestEdge(60, 896)(img).shape == (60, 80, 3)
+
+
+def _fake_instances(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    i = Instances((10, 10))
+    i.pred_boxes = Boxes(torch.rand(n, 4, generator=g) * 10)
+    i.scores = torch.rand(n, generator=g)
+    i.pred_classes = torch.randint(0, 50, (n,), generator=g)
+    i.pred_bbox3D = torch.randn(n, 8, 3, generator=g)
+    i.pred_center_cam = torch.randn(n, 3, generator=g)
+    i.pred_center_2D = torch.randn(n, 2, generator=g)
+    i.pred_dimensions = torch.rand(n, 3, generator=g)
+    i.pred_pose = torch.randn(n, 3, 3, generator=g)
+    return i
+
+
+def test_records_json_equals_instances_to_coco_json():
+    from ovmono3d_amd.evaluation.omni3d_evaluation import _json_of_records, _records_of, instances_to_coco_json
+    inst = _fake_instances(5, 1)
+    a = instances_to_coco_json(inst, 42)
+    b = _json_of_records(_records_of(inst, 0), 42)
+    assert len(a) == len(b) == 5
+    for x, y in zip(a, b):
+        assert x["image_id"] == y["image_id"] == 42 and x["category_id"] == y["category_id"]
+        for k in ("bbox", "bbox3D", "center_cam", "center_2D", "dimensions", "pose"):
+            assert np.allclose(np.asarray(x[k]), np.asarray(y[k]), atol=1e-6), k
+        assert abs(x["score"] - y["score"]) < 1e-7 and abs(x["depth"] - y["depth"]) < 1e-7
+    assert instances_to_coco_json(Instances((4, 4)), 1) == []
+
+
+class _StubModel:
+    """Deterministic stand-in: image i yields (image_id % 3) detections."""
+
+    def eval(self):
+        return self
+
+    def __call__(self, inputs, prompt_depth=None):
+        return [{"instances": _fake_instances(int(x["image_id"]) % 3, int(x["image_id"]))} for x in inputs]
+
+
+class _Loader(list):
+    pass
+
+
+def _make_loader(n, rank, world):
+    from ovmono3d_amd import lib
+    b, e = lib.shard_range(n, rank, world)
+    return _Loader([[{"image_id": i, "K": np.eye(3).tolist(), "width": 4, "height": 4}] for i in range(b, e)])
+
+
+def test_inference_on_dataset_single_process():
+    from ovmono3d_amd.evaluation import inference_on_dataset
+    res = inference_on_dataset(_StubModel(), _make_loader(7, 0, 1))
+    assert [r["image_id"] for r in res] == list(range(7))
+    assert [len(r["instances"]) for r in res] == [i % 3 for i in range(7)]
+    assert set(res[2]["instances"][0]) >= {"image_id", "category_id", "bbox", "score", "bbox3D", "center_cam", "depth"}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ovmono3d_amd.evaluation import inference_on_dataset
+    res = inference_on_dataset(_StubModel(), _make_loader(n, rank, world))
+    if rank == 0:
+        q.put(json.dumps([[r["image_id"], len(r["instances"]), r["instances"][0]["score"] if r["instances"] else None] for r in res]))
+    else:
+        assert res == []
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_inference_on_dataset_two_ranks_gloo():
+    world, n = 2, 9
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = json.loads(q.get(timeout=120))
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    from ovmono3d_amd.evaluation import inference_on_dataset
+    ref = inference_on_dataset(_StubModel(), _make_loader(n, 0, 1))
+    exp = [[r["image_id"], len(r["instances"]), r["instances"][0]["score"] if r["instances"] else None] for r in ref]
+    assert got == exp
+
+
+def test_synthetic_checkpoint_uri_and_key_tree():
+    """DetectionCheckpointer accepts synthetic://<arch>?seed=N; keys follow the reference module tree (nohup.out:563-684)."""
+    from ovmono3d_amd.util.synth_weights import synth_state_dict
+    sd = synth_state_dict("vittest14", seed=0)
+    for k in ("backbone.net.vit.blocks.0.attn.qkv.weight", "backbone.simfp_2.0.weight", "backbone.simfp_4.2.norm.bias",
+              "backbone.net.depth_fusion.weight", "proposal_generator.rpn_head.anchor_deltas.weight",
+              "roi_heads.box_predictor.bbox_pred.weight", "roi_heads.cube_head.feature_generator.fc1.weight",
+              "roi_heads.cube_head.bbox_3D_uncertainty.bias"):
+        assert k in sd, k
+    assert sd["backbone.simfp_2.0.weight"].shape == (128, 64, 2, 2)
+    assert sd["roi_heads.cube_head.feature_generator.fc1.weight"].shape == (1024, 12544)

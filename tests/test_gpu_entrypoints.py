@@ -1,0 +1,76 @@
+"""GPU: the drop-in entry points run end to end on synthetic data (demo.py with an oracle-2D boxes file,
+inference_on_dataset over a tiny Omni3D-format dataset)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from common import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_images(folder, n=2):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    names = []
+    for i in range(n):
+        arr = rng.integers(0, 255, (120 + 20 * i, 160, 3), dtype=np.uint8)
+        name = f"img{i:03d}"
+        Image.fromarray(arr).save(os.path.join(folder, name + ".png"))
+        names.append(name)
+    return names
+
+
+def test_demo_with_boxes_file(device, tmp_path):
+    inp = tmp_path / "in"; inp.mkdir()
+    out = tmp_path / "out"
+    names = _write_images(str(inp))
+    labels = {n: ["chair", "table"] for n in names}
+    boxes = {n: [{"bbox": [20, 20, 60, 50], "category_id": 0, "score": 0.9}, {"bbox": [70, 40, 50, 60], "category_id": 1, "score": 0.8}]
+             for n in names}
+    (tmp_path / "labels.json").write_text(json.dumps(labels))
+    (tmp_path / "boxes.json").write_text(json.dumps(boxes))
+    cmd = [sys.executable, os.path.join(ROOT, "demo", "demo.py"), "--config-file", os.path.join(ROOT, "configs", "OVMono3D_dinov2_SFP.yaml"),
+           "--input-folder", str(inp), "--labels-file", str(tmp_path / "labels.json"), "--boxes-file", str(tmp_path / "boxes.json"),
+           "--threshold", "0.0", "MODEL.DINO.MODEL_NAME", "vittest14", "MODEL.FPN.SQUARE_PAD", "224", "INPUT.MIN_SIZE_TEST", "140",
+           "INPUT.MAX_SIZE_TEST", "224", "MODEL.WEIGHTS", "synthetic://vittest14?seed=3", "OUTPUT_DIR", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for n in names:
+        d = json.loads((out / f"{n}_dets.json").read_text())
+        assert len(d["detections"]) == 2 and d["detections"][0]["category"] in ("chair", "table")
+        assert np.asarray(d["detections"][0]["corners3D"]).shape == (8, 3)
+
+
+def test_gdino_head_demo_fails_loudly_without_detector(device, tmp_path):
+    inp = tmp_path / "in"; inp.mkdir()
+    names = _write_images(str(inp), 1)
+    (tmp_path / "labels.json").write_text(json.dumps({names[0]: ["chair"]}))
+    cmd = [sys.executable, os.path.join(ROOT, "demo", "demo.py"), "--config-file", os.path.join(ROOT, "configs", "OVMono3D_dinov2_SFP.yaml"),
+           "--input-folder", str(inp), "--labels-file", str(tmp_path / "labels.json"), "MODEL.ROI_HEADS.NAME", "ROIHeads3DGDINO",
+           "MODEL.DINO.MODEL_NAME", "vittest14", "MODEL.FPN.SQUARE_PAD", "224", "INPUT.MIN_SIZE_TEST", "140", "INPUT.MAX_SIZE_TEST", "224",
+           "MODEL.WEIGHTS", "synthetic://vittest14?seed=3", "OUTPUT_DIR", str(tmp_path / "o")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "NotImplementedError" in r.stderr
+
+
+def test_eval_only_entry_point(device, tmp_path):
+    root = tmp_path / "datasets"; (root / "Omni3D").mkdir(parents=True); (root / "imgs").mkdir()
+    names = _write_images(str(root / "imgs"), 3)
+    images = [{"id": 100 + i, "file_path": f"imgs/{n}.png", "width": 160, "height": 120 + 20 * i, "dataset_id": 0,
+               "K": [[300.0, 0, 80], [0, 300.0, 60 + 10 * i], [0, 0, 1]]} for i, n in enumerate(names)]
+    (root / "Omni3D" / "Objectron_test.json").write_text(json.dumps({"images": images, "annotations": [], "categories": []}))
+    out = tmp_path / "out"
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "train_net.py"), "--eval-only", "--config-file",
+           os.path.join(ROOT, "configs", "OVMono3D_dinov2_SFP.yaml"), "--datasets-root", str(root / "Omni3D"), "--image-root", str(root),
+           "MODEL.DINO.MODEL_NAME", "vittest14", "MODEL.FPN.SQUARE_PAD", "224", "INPUT.MIN_SIZE_TEST", "140", "INPUT.MAX_SIZE_TEST", "224",
+           "MODEL.WEIGHTS", "synthetic://vittest14?seed=3", "OUTPUT_DIR", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads((out / "inference" / "iter_final" / "Objectron_test" / "omni_instances_results.json").read_text())
+    assert len(res) > 0 and {"image_id", "category_id", "bbox", "score", "bbox3D", "pose", "depth"} <= set(res[0])
+    assert {r_["image_id"] for r_ in res} <= {100, 101, 102}

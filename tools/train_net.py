@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Drop-in for ``tools/train_net.py --eval-only`` of the reference (tools/train_net.py:359-459,561-570) on the
+native path: one process per GPU, contiguous image shards per rank, the per-rank loop of
+``inference_on_dataset`` and one gather of detection records to rank 0, predictions saved as JSON per
+dataset (the reference's ``eval_helper.save_predictions``, tools/train_net.py:108-109).
+
+Launch: ``python tools/train_net.py --eval-only --config-file configs/OVMono3D_dinov2_SFP.yaml --num-gpus N
+MODEL.WEIGHTS <ckpt> OUTPUT_DIR <dir>`` (N > 1 re-launches itself under torch.distributed.run, one rank
+per GPU over RCCL). Training (``do_train``) and the AP evaluators are out of scope.
+
+Deviations from the fork, both restoring upstream intent: oracle-2D boxes are
+forwarded to the model when TEST.ORACLE2D is set and the oracle file exists, and TEST.CAT_MODE selects the mode.
+"""
+import argparse
+import json
+import logging
+import os
+import subprocess
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from ovmono3d_amd.checkpoint import DetectionCheckpointer  # noqa: E402
+from ovmono3d_amd.data import (DatasetMapper3D, build_detection_test_loader, load_omni3d_json,  # noqa: E402
+                               merge_oracle2d_to_detection_dicts)
+from ovmono3d_amd.defaults import make_cfg  # noqa: E402
+from ovmono3d_amd.evaluation import Omni3DEvaluator, inference_on_dataset  # noqa: E402
+from ovmono3d_amd.evaluation.distributed import get_rank, get_world_size  # noqa: E402
+from ovmono3d_amd.modeling import build_model  # noqa: E402
+
+logger = logging.getLogger("cubercnn")
+
+
+def do_test(cfg, model, mode="base", datasets_root="datasets/Omni3D", image_root="datasets", depth_dir=None):
+    if mode == "novel":
+        names = cfg.DATASETS.TEST_NOVEL
+    elif mode == "base":
+        names = cfg.DATASETS.TEST_BASE
+    else:
+        raise ValueError("wrong mode")
+    out_dir = os.path.join(cfg.OUTPUT_DIR, "inference", "iter_final")
+    for name in names:
+        dicts = load_omni3d_json(os.path.join(datasets_root, name + ".json"), image_root)
+        if cfg.TEST.ORACLE2D:
+            files = cfg.DATASETS.ORACLE2D_FILES.get(cfg.DATASETS.ORACLE2D_FILES.EVAL_MODE, {})
+            path = (files.get(mode, {}) or {}).get(name) if hasattr(files, "get") else None
+            if path and os.path.exists(path):
+                merge_oracle2d_to_detection_dicts(dicts, path)
+        loader = build_detection_test_loader(cfg, dicts, DatasetMapper3D(cfg, False, depth_dir), get_rank(), get_world_size())
+        results = inference_on_dataset(model, loader, Omni3DEvaluator(name, out_dir))
+        if get_rank() == 0:
+            os.makedirs(os.path.join(out_dir, name), exist_ok=True)
+            with open(os.path.join(out_dir, name, "omni_instances_results.json"), "w") as f:
+                json.dump([inst for r in results for inst in r["instances"]], f)
+            logger.info("%s: %d images, %d detections", name, len(results), sum(len(r["instances"]) for r in results))
+
+
+def main(args):
+    logging.basicConfig(level=logging.INFO)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    cfg = make_cfg(args.config_file, args.opts)
+    if not args.eval_only:
+        raise SystemExit("only --eval-only is supported by the native inference path (training is out of scope)")
+    model = build_model(cfg, device=torch.device("cuda", local_rank))
+    DetectionCheckpointer(model, save_dir=cfg.OUTPUT_DIR).resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume)
+    if cfg.TEST.CAT_MODE == "all":
+        do_test(cfg, model, "novel", args.datasets_root, args.image_root, args.depth_dir)
+        do_test(cfg, model, "base", args.datasets_root, args.image_root, args.depth_dir)
+    else:
+        do_test(cfg, model, cfg.TEST.CAT_MODE, args.datasets_root, args.image_root, args.depth_dir)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def default_argument_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--config-file", default="", metavar="FILE")
+    p.add_argument("--resume", action="store_true")
+    p.add_argument("--eval-only", action="store_true")
+    p.add_argument("--num-gpus", type=int, default=1)
+    p.add_argument("--num-machines", type=int, default=1)
+    p.add_argument("--machine-rank", type=int, default=0)
+    p.add_argument("--dist-url", default="tcp://127.0.0.1:29500")
+    p.add_argument("--datasets-root", default="datasets/Omni3D", help="(native build) folder of the Omni3D JSON files")
+    p.add_argument("--image-root", default="datasets")
+    p.add_argument("--depth-dir", default=None, help="(native build) folder of depth-prompt .npz files")
+    p.add_argument("opts", default=None, nargs=argparse.REMAINDER)
+    return p
+
+
+if __name__ == "__main__":
+    args = default_argument_parser().parse_args()
+    if args.num_gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the reference's launch() spawns one process per GPU (tools/train_net.py:563-570); here the same via
+        # torch.distributed.run, started as a child process before anything touches the GPU
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.num_gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", "29511", os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    main(args)
