@@ -162,7 +162,7 @@ int ovm_host_shard_range(int64_t n_items, int32_t rank, int32_t world, int64_t* 
 
 /* --- kernel-level entry points (parity tests and micro-benchmarks call the same kernels the model
  * path launches). All pointers device; "split" fp16 tensors are a hi array and an optional lo array
- * (x ~= hi + lo * 2^-11). */
+ * (x ~= hi + lo). */
 int ovm_op_split_f16(const float* x, int64_t n, uint16_t* hi, uint16_t* lo, ovm_stream_t stream);
 int ovm_op_gemm(const uint16_t* a_hi, const uint16_t* a_lo, int32_t lda, const uint16_t* w_hi, const uint16_t* w_lo,
                 int32_t M, int32_t N, int32_t K, const float* bias, int32_t relu, float* c, int32_t ldc,
@@ -180,6 +180,9 @@ int ovm_op_cube_decode(const float* head13, int32_t ld, const float* boxes, cons
                        int32_t postprocess, OvmDet3D* rec, int32_t* keep, ovm_stream_t stream);
 int ovm_op_nms(const float* boxes, const float* scores, int32_t n, float thresh, int32_t* keep_idx, int32_t* n_keep,
                ovm_stream_t stream);
+
+/* tuning knob for experiments: key "gemm_bm" = 0 (heuristic) | 128 | 256 */
+int ovm_tune_set(const char* key, int32_t value);
 
 /* --- introspection for tests: copy a named intermediate of the last forward into dst (device).
  * names: "tokens" [B*T][D] fp32, "p2" / "p3" / "p4". Returns the element count or a negative error. */

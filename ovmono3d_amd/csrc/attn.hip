@@ -11,7 +11,7 @@
 // V^T is stored with the token order permuted inside groups of 16 (bits 2<->3) by the QKV epilogue so
 // the PV A-fragment, whose k order is {4h..4h+3, 8+4h..8+4h+3}, is a single ds_read_b128.
 //
-// NPASS=3 uses split operands for both products (see common.hpp) and two accumulator sets.
+// NPASS=3 uses split operands (hi + lo) for both products, three MFMAs per product into the same accumulator.
 #include "kernels.hpp"
 
 namespace ovm {
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   constexpr int NPART = (NPASS == 3) ? 4 : 2;          // Khi, Vhi, (Klo, Vlo)
   constexpr int STAGE = PART * NPART;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nqb = (p.T + 127) >> 7;
+  const int nqb = (p.Tq + 127) >> 7;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = bid / nqb, qb = bid - bh * nqb;
   const int b = bh / p.heads, head = bh - b * p.heads;
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 
   // ---- Q^T fragments from HBM (B operand: lane holds Q[q][16s + 8h + j]) ----
   int q = qb * 128 + wave * 32 + r;
-  const bool q_ok = q < T;
+  const bool q_ok = q < p.Tq;
   if (!q_ok) q = T - 1;
   half8 qh[4], ql[4];
 #pragma unroll
@@ -67,11 +67,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     }
   };
 
-  f32x16 o0[2], o1[2];
+  f32x16 o0[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { o0[t][i] = 0.f; o1[t][i] = 0.f; }
+    for (int i = 0; i < 16; ++i) o0[t][i] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
 
   const int nt = (T + 63) >> 6;
@@ -84,22 +84,22 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     const char* base = smem + cur * STAGE;
 
     // ---- S^T = K Q^T : two 32-key tiles ----
-    f32x16 s0[2], s1[2];
+    f32x16 s0[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { s0[i][e] = 0.f; s1[i][e] = 0.f; }
+      for (int e = 0; e < 16; ++e) s0[i][e] = 0.f;
       const int row = 32 * i + r;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int off = row * 128 + swz128(row, 2 * s + h) * 16;
         const half8 kh = *(const half8*)(base + off);
-        s0[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], s0[i], 0, 0, 0);
         if (NPASS == 3) {
           const half8 kl = *(const half8*)(base + 2 * PART + off);
-          s1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], s1[i], 0, 0, 0);
-          s1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], s1[i], 0, 0, 0);
+          s0[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], s0[i], 0, 0, 0);
+          s0[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], s0[i], 0, 0, 0);
         }
+        s0[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], s0[i], 0, 0, 0);
       }
     }
     // ---- online softmax over the 64 keys of this tile (keys >= T masked) ----
@@ -111,7 +111,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         float v = s0[i][e];
-        if (NPASS == 3) v += s1[i][e] * kLoInv;
         if (tail) {
           const int key = kbase + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
           if (key >= T) v = -1e30f;
@@ -139,7 +138,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { o0[t][e] *= alpha; if (NPASS == 3) o1[t][e] *= alpha; }
+      for (int e = 0; e < 16; ++e) o0[t][e] *= alpha;
 
     // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -151,12 +150,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         for (int sp = 0; sp < 2; ++sp) {
           const int off = row * 128 + swz128(row, 4 * i + 2 * sp + h) * 16;
           const half8 vh = *(const half8*)(base + PART + off);
-          o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[i][sp], o0[t], 0, 0, 0);
           if (NPASS == 3) {
             const half8 vl = *(const half8*)(base + 3 * PART + off);
-            o1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[i][sp], o1[t], 0, 0, 0);
-            o1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[i][sp], o1[t], 0, 0, 0);
+            o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[i][sp], o0[t], 0, 0, 0);
+            o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[i][sp], o0[t], 0, 0, 0);
           }
+          o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[i][sp], o0[t], 0, 0, 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -176,9 +175,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         half4 hv, lv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v = o0[t][4 * g + e];
-          if (NPASS == 3) v += o1[t][4 * g + e] * kLoInv;
-          half_t hh, ll; split_f16(v * inv, hh, ll); hv[e] = hh; lv[e] = ll;
+          half_t hh, ll; split_f16(o0[t][4 * g + e] * inv, hh, ll); hv[e] = hh; lv[e] = ll;
         }
         const int d = 32 * t + 8 * g + 4 * h;
         *(half4*)(p.Ohi + orow + d) = hv;
@@ -187,17 +184,116 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tail query rows. T = 4097 leaves ONE query past 32 blocks of 128; as a 33rd block per head it would
+// add a second, nearly empty round of workgroups. Up to 8 leftover queries per (batch, head) are handled
+// here instead: one workgroup per (query, batch*head), scores and probabilities in LDS, fp32 FMAs on the
+// reconstructed (hi + lo) operands.
+// ---------------------------------------------------------------------------------------------
+template <int NPASS>
+__global__ __launch_bounds__(256) void attn_tail_kernel(const AttnParams p, int q_begin) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sc = (float*)smem;                       // [Tpad] scores -> probabilities, in V^T's permuted token order
+  __shared__ float red[8];
+  __shared__ float part[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.x, q = q_begin + blockIdx.y;
+  const int b = bh / p.heads, head = bh - b * p.heads;
+  const int T = p.T, Tpad = p.Tpad;
+  const size_t qk_base = (size_t)bh * T * 64;
+  const size_t v_base = (size_t)bh * 64 * Tpad;
+  float qv[64];
+#pragma unroll
+  for (int d = 0; d < 64; ++d) {
+    qv[d] = (float)p.Qhi[qk_base + (size_t)q * 64 + d];
+    if (NPASS == 3) qv[d] += (float)p.Qlo[qk_base + (size_t)q * 64 + d];
+  }
+  float mx = -1e30f;
+  for (int t = tid; t < Tpad; t += 256) {
+    float s = -1e30f;
+    if (t < T) {
+      s = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const half8 kh = *(const half8*)(p.Khi + qk_base + (size_t)t * 64 + c * 8);
+        half8 kl;
+        if (NPASS == 3) kl = *(const half8*)(p.Klo + qk_base + (size_t)t * 64 + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float kv = (float)kh[j];
+          if (NPASS == 3) kv += (float)kl[j];
+          s = fmaf(qv[c * 8 + j], kv, s);
+        }
+      }
+    }
+    const int tp = (t & ~15) | (t & 3) | ((t & 4) << 1) | ((t & 8) >> 1);
+    sc[tp] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int t = tid; t < Tpad; t += 256) {
+    const float e = __expf(sc[t] - mx);          // masked slots hold -1e30 -> 0
+    sc[t] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  // O[d] = sum_t p[t] V[t][d]; wave w covers a quarter of the (permuted) token axis, lane = d
+  const int d = lane;
+  const int q4 = Tpad / 4;                        // Tpad % 64 == 0
+  float o = 0.f;
+  const half_t* vh = p.Vhi + v_base + (size_t)d * Tpad + wave * q4;
+  const half_t* vl = (NPASS == 3) ? p.Vlo + v_base + (size_t)d * Tpad + wave * q4 : nullptr;
+  const float* pr = sc + wave * q4;
+  for (int j = 0; j < q4; j += 8) {
+    const half8 h8 = *(const half8*)(vh + j);
+    half8 l8;
+    if (NPASS == 3) l8 = *(const half8*)(vl + j);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = (float)h8[e];
+      if (NPASS == 3) v += (float)l8[e];
+      o = fmaf(pr[j + e], v, o);
+    }
+  }
+  part[wave][d] = o;
+  __syncthreads();
+  if (wave == 0) {
+    const float r = (part[0][d] + part[1][d] + part[2][d] + part[3][d]) * inv;
+    half_t hh, ll; split_f16(r, hh, ll);
+    const size_t oo = ((size_t)b * T + q) * p.ldo + head * 64 + d;
+    p.Ohi[oo] = hh;
+    if (p.Olo) p.Olo[oo] = ll;
+  }
+}
+
+static int g_attn_tail = 1;
+void attn_set_tail_rows(int on) { g_attn_tail = on; }
+
 int launch_attention(const AttnParams& p, int npass, hipStream_t s) {
   if (p.T <= 0 || p.B <= 0) return OVM_OK;
   if (p.Tpad % 64 != 0 || p.Tpad < ((p.T + 63) / 64) * 64) return OVM_ERR_SHAPE;
-  const int nqb = (p.T + 127) / 128;
-  const dim3 grid(nqb * p.heads * p.B), block(256);
-  if (npass == 3) {
-    if (!p.Qlo || !p.Klo || !p.Vlo) return OVM_ERR_INVALID;
-    hipLaunchKernelGGL(attn_kernel<3>, grid, block, 2 * 4 * 64 * 128, s, p);
+  if (npass == 3 && (!p.Qlo || !p.Klo || !p.Vlo)) return OVM_ERR_INVALID;
+  AttnParams pm = p;
+  const int tail = p.T % 128;
+  if (g_attn_tail && tail > 0 && tail <= 8 && p.T > 128 && p.Tpad * 4 <= 60000) {
+    const dim3 tg(p.heads * p.B, tail);
+    if (npass == 3) hipLaunchKernelGGL(attn_tail_kernel<3>, tg, dim3(256), p.Tpad * 4, s, p, p.T - tail);
+    else hipLaunchKernelGGL(attn_tail_kernel<1>, tg, dim3(256), p.Tpad * 4, s, p, p.T - tail);
+    pm.Tq = p.T - tail;
   } else {
-    hipLaunchKernelGGL(attn_kernel<1>, grid, block, 2 * 2 * 64 * 128, s, p);
+    pm.Tq = p.T;
   }
+  const int nqb = (pm.Tq + 127) / 128;
+  const dim3 grid(nqb * p.heads * p.B), block(256);
+  if (npass == 3) hipLaunchKernelGGL(attn_kernel<3>, grid, block, 2 * 4 * 64 * 128, s, pm);
+  else hipLaunchKernelGGL(attn_kernel<1>, grid, block, 2 * 2 * 64 * 128, s, pm);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 

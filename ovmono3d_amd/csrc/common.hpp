@@ -13,15 +13,29 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// Split-precision operand: x ~= hi + lo * 2^-11, hi = fp16(x), lo = fp16((x - hi) * 2^11).
+// Split-precision operand: x ~= hi + lo, hi = fp16(x), lo = fp16(x - hi) (22 significant bits; lo may be an
+// fp16 subnormal - v_mfma_*_f16 honours fp16 denormal inputs on gfx950, verified on hardware).
 // One-pass mode (precision "f16") uses hi only; three-pass mode ("f16x3") accumulates
-//   acc0 += Ah*Wh ; acc1 += Al*Wh + Ah*Wl ; C = acc0 + acc1 * 2^-11      (Al*Wl ~ 2^-22 dropped)
-constexpr float kLoScale = 2048.0f;
-constexpr float kLoInv = 1.0f / 2048.0f;
+//   acc += Ah*Wh + Al*Wh + Ah*Wl          (the Al*Wl term, ~2^-22 relative, is dropped)
+// into ONE fp32 accumulator, so the split costs MFMA issue slots but no extra registers.
+constexpr float kLoScale = 1.0f;
+constexpr float kLoInv = 1.0f;
+
+// f32 -> f16, round-to-nearest-even, fp16 subnormal results preserved. Written as the scalar
+// v_cvt_f16_f32: when hipcc pairs two conversions into gfx950's v_cvt_pk_f16_f32 the subnormal results
+// come back as zero (measured: the split's lo parts and tiny attention outputs were lost), which would
+// silently cut the f16x3 mode back to ~fp16 accuracy for |x| < 2^-3.
+// The leading s_nop covers the trans->VALU wait state (v_exp_f32 etc. feeding the conversion): hipcc pads
+// hazards for its own instructions only, not for ones inside an asm string.
+__device__ __forceinline__ half_t cvt_f16_rn(float x) {
+  uint32_t r;
+  asm volatile("s_nop 1\n\tv_cvt_f16_f32 %0, %1" : "=v"(r) : "v"(x));
+  return __builtin_bit_cast(half_t, (uint16_t)(r & 0xFFFFu));
+}
 
 __device__ __forceinline__ void split_f16(float x, half_t& hi, half_t& lo) {
-  hi = (half_t)x;
-  lo = (half_t)((x - (float)hi) * kLoScale);
+  hi = cvt_f16_rn(x);
+  lo = cvt_f16_rn(x - (float)hi);
 }
 
 // 16-byte async global -> LDS copy (global_load_lds_dwordx4). LDS destination is

@@ -3,22 +3,52 @@
 
 namespace ovm {
 
-template <int NPASS, int BK, int EPI, int AMODE>
+static int g_force_bm = 0;
+static int g_tail_rows = 1;
+void gemm_set_force_bm(int bm) { g_force_bm = bm; }
+void gemm_set_tail_rows(int on) { g_tail_rows = on; }
+
+template <int NPASS, int BK, int BM, int EPI, int AMODE>
 static int launch_one(const GemmParams& p, hipStream_t s) {
-  constexpr int NPART = (NPASS == 3) ? 4 : 2;
-  constexpr int smem = 2 * NPART * 128 * BK * 2;
-  const int tiles_m = (p.M + 127) / 128;
+  constexpr int smem = 2 * (BM + 128) * BK * 2 * ((NPASS == 3) ? 2 : 1);
+  const int tiles_m = (p.M + BM - 1) / BM;
   const int tiles_n = (p.N + 127) / 128;
-  if (p.M <= 0 || p.N <= 0) return OVM_OK;
   if (p.K % BK != 0) return OVM_ERR_SHAPE;
-  hipLaunchKernelGGL((gemm_kernel<NPASS, BK, EPI, AMODE>), dim3(tiles_m * tiles_n), dim3(256), smem, s, p);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (smem > 65536 &&
+        hipFuncSetAttribute((const void*)gemm_kernel<NPASS, BK, BM, EPI, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return OVM_ERR_HIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<NPASS, BK, BM, EPI, AMODE>), dim3(tiles_m * tiles_n), dim3(BM * 2), smem, s, p);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 
+// Tile height: 256 rows halve the W-panel traffic per FLOP; 128 rows give twice the workgroups. Use the tall
+// tile when it still yields at least ~one full wave of workgroups over the 256 CUs.
+static int pick_bm(const GemmParams& p) {
+  if (g_force_bm == 128 || g_force_bm == 256) return g_force_bm;
+  const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
+  return tiles256 >= 224 ? 256 : 128;
+}
+
 template <int EPI, int AMODE>
-static int launch_prec(const GemmParams& p, int npass, hipStream_t s) {
-  if (npass == 3) return launch_one<3, 32, EPI, AMODE>(p, s);
-  return launch_one<1, 64, EPI, AMODE>(p, s);
+static int launch_prec(const GemmParams& p0, int npass, hipStream_t s) {
+  if (p0.M <= 0 || p0.N <= 0) return OVM_OK;
+  GemmParams p = p0;
+  const int tail = p0.M % 128;
+  if (g_tail_rows && tail > 0 && tail <= 8 && p0.M > 128 && p0.K % 64 == 0) {
+    // leftover rows (e.g. the cls token of the 4097-token canvas) go to the dot-product kernel
+    const int m_begin = p0.M - tail;
+    const dim3 grid((p0.N + 15) / 16, tail);
+    if (npass == 3) hipLaunchKernelGGL((gemm_tail_kernel<3, EPI, AMODE>), grid, dim3(256), 0, s, p0, m_begin);
+    else hipLaunchKernelGGL((gemm_tail_kernel<1, EPI, AMODE>), grid, dim3(256), 0, s, p0, m_begin);
+    p.M = m_begin;
+  }
+  const int bm = pick_bm(p);
+  if (npass == 3) return bm == 256 ? launch_one<3, 32, 256, EPI, AMODE>(p, s) : launch_one<3, 32, 128, EPI, AMODE>(p, s);
+  return bm == 256 ? launch_one<1, 64, 256, EPI, AMODE>(p, s) : launch_one<1, 64, 128, EPI, AMODE>(p, s);
 }
 
 int launch_gemm(const GemmParams& p, int npass, int epi, int amode, hipStream_t s) {

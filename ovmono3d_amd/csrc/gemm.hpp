@@ -1,14 +1,14 @@
 // MFMA GEMM for gfx950: C[m][n] = sum_k A[m][k] * W[n][k]   (both operands K-contiguous fp16)
 //
-//  * 128x128 block tile, 256 threads = 4 waves in 2(M) x 2(N), each wave 64x64 = 4x4 MFMA tiles of
+//  * BM x 128 block tile (BM = 128 or 256; 4 or 8 waves as (BM/64)(M) x 2(N)), each wave 64x64 = 4x4 MFMA tiles of
 //    v_mfma_f32_16x16x32_f16 (W rows on the MFMA "A" side, activation rows on the "B" side, so a
 //    lane's 4 accumulator registers run along n: 16-byte epilogue vectors).
 //  * Operands staged global -> LDS with global_load_lds_dwordx4 (no VGPR round trip), two LDS
 //    stages; swizzle applied on the per-lane SOURCE address and again on the ds_read_b128 address
 //    (LDS image itself is lane-linear, as the DMA requires).
-//  * NPASS=1: plain fp16 operands, fp32 accumulate.  NPASS=3: split operands (hi + lo*2^-11),
-//    three MFMAs per product into two accumulators - fp32-class accuracy at 1/3 of the fp16 rate
-//    (still ~5x the fp32-MFMA rate).
+//  * NPASS=1: plain fp16 operands, fp32 accumulate.  NPASS=3: split operands (hi + lo), three MFMAs per
+//    product into the same accumulator - fp32-class accuracy at 1/3 of the fp16 rate (still ~5x the
+//    fp32-MFMA rate).
 //  * AMODE selects how a row of A is addressed: dense row-major, or implicit-GEMM 3x3 convolution
 //    over a zero-bordered NHWC fp16 image (k = tap*C + c).
 //  * EPI selects the fused epilogue (bias/LayerScale/residual, GELU, QKV head split with V^T
@@ -167,36 +167,51 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32
   }
 }
 
-template <int NPASS, int BK, int EPI, int AMODE>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+template <int NPASS, int BK, int BM, int EPI, int AMODE>
+__global__ __launch_bounds__(BM * 2) void gemm_kernel(const GemmParams p) {
+  // Block tile BM x 128 (BM = 128: 4 waves, BM = 256: 8 waves); every wave owns a 64 x 64 sub-tile.
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = BM / 32;                     // waves per block
   constexpr int ROWB = BK * 2;                    // bytes per LDS row
-  constexpr int PART = 128 * ROWB;                // bytes per operand part
-  constexpr int NPART = (NPASS == 3) ? 4 : 2;     // Ahi, Whi, (Alo, Wlo)
-  constexpr int STAGE = PART * NPART;
+  constexpr int PART_A = BM * ROWB, PART_W = 128 * ROWB;
+  constexpr int STAGE = (PART_A + PART_W) * ((NPASS == 3) ? 2 : 1);
+  constexpr int OFF_AH = 0, OFF_WH = PART_A, OFF_AL = PART_A + PART_W, OFF_WL = 2 * PART_A + PART_W;
   constexpr int ROWS_PER_INSTR = 1024 / ROWB;     // rows one wave-wide DMA covers (8 or 16)
   constexpr int CH = ROWB / 16;                   // 16-byte chunks per row (8 or 4)
-  constexpr int INSTR_PER_WAVE = 128 / ROWS_PER_INSTR / 4;   // per part (4 or 2)
+  constexpr int IA = BM / ROWS_PER_INSTR / NW;    // A DMA instructions per wave per part
+  constexpr int IW = (128 / ROWS_PER_INSTR + NW - 1) / NW;   // W DMA instructions per wave per part (may be partial)
+  constexpr int NIW = 128 / ROWS_PER_INSTR;       // total W instructions per part
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_m = (p.M + 127) >> 7;
-  const int ntile_n = gridDim.x / tiles_m;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = bid / tiles_m, tm = bid - tn * tiles_m;
-  (void)ntile_n;
-  const int m0 = tm * 128, n0 = tn * 128;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = gridDim.x / tiles_m;
+  // XCD-aware remap, then grouped ordering (8 row-tiles per group) so the tiles that run concurrently on one
+  // XCD form a compact 2-D patch: each A / W k-slice is fetched into that XCD's L2 once and reused.
+  int pid = xcd_remap(blockIdx.x, gridDim.x);
+  constexpr int GROUP_M = 8;
+  const int in_group = GROUP_M * tiles_n;
+  const int gid = pid / in_group;
+  const int first_m = gid * GROUP_M;
+  const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+  const int tm = first_m + (pid % in_group) % gsz;
+  const int tn = (pid % in_group) / gsz;
+  const int m0 = tm * BM, n0 = tn * 128;
   const int wm = wave >> 1, wn = wave & 1;
 
-  // ---- per-lane DMA source offsets (elements), fixed over k ----
-  uint32_t aoff[INSTR_PER_WAVE], woff[INSTR_PER_WAVE];
+  uint32_t aoff[IA], woff[IW];
 #pragma unroll
-  for (int t = 0; t < INSTR_PER_WAVE; ++t) {
-    const int instr = wave + 4 * t;
+  for (int t = 0; t < IA; ++t) {
+    const int instr = wave + NW * t;
     const int row = instr * ROWS_PER_INSTR + lane / CH;
-    const int slot = lane % CH;
-    const int chunk = swz_slot<BK>(row, slot);      // involution: slot -> source chunk
+    const int chunk = swz_slot<BK>(row, lane % CH);
     int m = m0 + row; if (m > p.M - 1) m = p.M - 1;
     aoff[t] = a_row_offset<AMODE>(p, m) + chunk * 8;
+  }
+#pragma unroll
+  for (int t = 0; t < IW; ++t) {
+    const int instr = wave + NW * t;
+    const int row = (instr % NIW) * ROWS_PER_INSTR + lane / CH;
+    const int chunk = swz_slot<BK>(row, lane % CH);
     woff[t] = (uint32_t)(n0 + row) * (uint32_t)p.K + chunk * 8;
   }
 
@@ -205,23 +220,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     const uint32_t ak = a_k_offset<AMODE>(p, kt * BK);
     const uint32_t wk = (uint32_t)(kt * BK);
 #pragma unroll
-    for (int t = 0; t < INSTR_PER_WAVE; ++t) {
-      const int instr = wave + 4 * t;
-      char* dst = base + instr * 1024;
-      glds16(p.Ahi + aoff[t] + ak, dst);
-      glds16(p.Whi + woff[t] + wk, dst + PART);
-      if (NPASS == 3) {
-        glds16(p.Alo + aoff[t] + ak, dst + 2 * PART);
-        glds16(p.Wlo + woff[t] + wk, dst + 3 * PART);
+    for (int t = 0; t < IA; ++t) {
+      char* dst = base + (wave + NW * t) * 1024;
+      glds16(p.Ahi + aoff[t] + ak, dst + OFF_AH);
+      if (NPASS == 3) glds16(p.Alo + aoff[t] + ak, dst + OFF_AL);
+    }
+#pragma unroll
+    for (int t = 0; t < IW; ++t) {
+      const int instr = wave + NW * t;
+      if (instr < NIW) {                           // wave-uniform
+        char* dst = base + instr * 1024;
+        glds16(p.Whi + woff[t] + wk, dst + OFF_WH);
+        if (NPASS == 3) glds16(p.Wlo + woff[t] + wk, dst + OFF_WL);
       }
     }
   };
 
-  f32x4 acc0[4][4], acc1[4][4];
+  f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { acc0[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
   stage(0, 0);
@@ -243,22 +262,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         const int rw = wn * 64 + i * 16 + fr;
         const int oa = ra * ROWB + swz_slot<BK>(ra, chunk) * 16;
         const int ow = rw * ROWB + swz_slot<BK>(rw, chunk) * 16;
-        ah[i] = *(const half8*)(base + oa);
-        wh[i] = *(const half8*)(base + PART + ow);
+        ah[i] = *(const half8*)(base + OFF_AH + oa);
+        wh[i] = *(const half8*)(base + OFF_WH + ow);
         if (NPASS == 3) {
-          al[i] = *(const half8*)(base + 2 * PART + oa);
-          wl[i] = *(const half8*)(base + 3 * PART + ow);
+          al[i] = *(const half8*)(base + OFF_AL + oa);
+          wl[i] = *(const half8*)(base + OFF_WL + ow);
         }
       }
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
-          acc0[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ni], ah[mi], acc0[ni][mi], 0, 0, 0);
           if (NPASS == 3) {
-            acc1[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ni], ah[mi], acc1[ni][mi], 0, 0, 0);
-            acc1[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ni], al[mi], acc1[ni][mi], 0, 0, 0);
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ni], ah[mi], acc[ni][mi], 0, 0, 0);
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ni], al[mi], acc[ni][mi], 0, 0, 0);
           }
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -274,17 +293,62 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int n = n0 + wn * 64 + ni * 16 + fq * 4;
-      f32x4 v = acc0[ni][mi];
-      if (NPASS == 3) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += acc1[ni][mi][r] * kLoInv;
-      }
-      epilogue4<EPI>(p, m, n, v);
+      epilogue4<EPI>(p, m, n, acc[ni][mi]);
     }
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tail rows: M = B*T is 4097 for the reference canvas (64x64 patches + cls), one row past a multiple of
+// the tile height. Running that row as a 33rd row of tiles costs a full extra round of workgroups on the
+// 256 CUs, so up to 8 leftover rows are computed by this wave-per-4-columns dot-product kernel instead
+// (fp32 FMA on the reconstructed hi+lo operands, same epilogues).
+// ---------------------------------------------------------------------------------------------
+template <int NPASS, int EPI, int AMODE>
+__global__ __launch_bounds__(256) void gemm_tail_kernel(const GemmParams p, int m_begin) {
+  const int lane = threadIdx.x & 63;
+  const int n = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+  const int m = m_begin + blockIdx.y;
+  if (n >= p.N || m >= p.M) return;
+  const uint32_t arow = a_row_offset<AMODE>(p, m);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = lane * 8; k0 < p.K; k0 += 512) {
+    const uint32_t ao = arow + a_k_offset<AMODE>(p, k0 & ~63) + (k0 & 63);
+    const half8 ah = *(const half8*)(p.Ahi + ao);
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = (float)ah[j];
+    if (NPASS == 3) {
+      const half8 al = *(const half8*)(p.Alo + ao);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += (float)al[j];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t wo = (size_t)(n + r) * p.K + k0;
+      const half8 wh = *(const half8*)(p.Whi + wo);
+      float w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = (float)wh[j];
+      if (NPASS == 3) {
+        const half8 wl = *(const half8*)(p.Wlo + wo);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] += (float)wl[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[r] = fmaf(a[j], w[j], acc[r]);
+    }
+  }
+  f32x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = wave_sum(acc[r]);
+  if (lane == 0) epilogue4<EPI>(p, m, n, v);
+}
+
 // Host launcher (defined in gemm.hip). npass in {1,3}.
 int launch_gemm(const GemmParams& p, int npass, int epi, int amode, hipStream_t stream);
+// Tile-height override for tuning (0 = heuristic): 128 or 256.
+void gemm_set_force_bm(int bm);
+void gemm_set_tail_rows(int on);
 
 }  // namespace ovm

@@ -21,6 +21,7 @@ struct AttnParams {
   const half_t *Qhi, *Qlo, *Khi, *Klo, *Vhi, *Vlo;   // Q,K [B][h][T][64]; V^T [B][h][64][Tpad] (permuted tokens)
   half_t *Ohi, *Olo; int ldo;                        // out rows b*T + t, column head*64 + d
   int B, heads, T, Tpad;
+  int Tq;                                            // query rows covered by the tiled kernel (set by the launcher)
 };
 
 struct RoiParams {
@@ -68,6 +69,7 @@ int launch_maxpool2(const half_t* Ihi, const half_t* Ilo, int B, int G, int D, h
 int launch_depth_resize(const float* Dp, int B, int Hd, int Wd, int G, float* out, hipStream_t s);
 int launch_zero(void* p, size_t bytes, hipStream_t s);
 int launch_attention(const AttnParams& p, int npass, hipStream_t s);
+void attn_set_tail_rows(int on);
 int launch_roi_align(const RoiParams& p, hipStream_t s);
 int launch_cube_decode(const CubeDecodeParams& p, hipStream_t s);
 int launch_compact_records(const float* rec, const int* keep, int n, int B, float* out, int* counts, hipStream_t s);

@@ -150,6 +150,15 @@ int ovm_op_cube_decode(const float* head13, int32_t ld, const float* boxes, cons
   return OVM_OK;
 }
 
+// Tuning knobs for experiments (not part of the stable surface): "gemm_bm" = 0 (heuristic) | 128 | 256.
+int ovm_tune_set(const char* key, int32_t value) {
+  if (!key) return OVM_ERR_INVALID;
+  if (!strcmp(key, "gemm_bm")) { gemm_set_force_bm(value); return OVM_OK; }
+  if (!strcmp(key, "gemm_tail")) { gemm_set_tail_rows(value); return OVM_OK; }
+  if (!strcmp(key, "attn_tail")) { attn_set_tail_rows(value); return OVM_OK; }
+  return OVM_ERR_INVALID;
+}
+
 int ovm_op_nms(const float* boxes, const float* scores, int32_t n, float thresh, int32_t* keep_idx, int32_t* n_keep,
                ovm_stream_t stream) {
   return launch_nms_single(boxes, scores, n, thresh, keep_idx, n_keep, (hipStream_t)stream);

@@ -1,0 +1,26 @@
+import sys, ctypes as C, torch, math
+sys.path.insert(0,'/root/repo')
+from ovmono3d_amd import lib
+L=lib.load(); dev=torch.device('cuda')
+def split(x):
+    hi=torch.empty(x.shape,dtype=torch.float16,device=dev); lo=torch.empty_like(hi)
+    L.ovm_op_split_f16(x.data_ptr(), x.numel(), hi.data_ptr(), lo.data_ptr(), None); return hi,lo
+M=4097
+for (N,K) in ((3072,1024),(1024,1024),(4096,1024),(1024,4096)):
+    A=torch.randn(M,K,device=dev); W=torch.randn(N,K,device=dev)/math.sqrt(K)
+    ah,al=split(A); wh,wl=split(W); Cc=torch.empty(M,N,device=dev)
+    for prec in (1,3):
+        for bm in (128,256):
+            L.ovm_tune_set(b"gemm_bm", bm)
+            for _ in range(3): L.ovm_op_gemm(ah.data_ptr(),al.data_ptr(),K,wh.data_ptr(),wl.data_ptr(),M,N,K,None,0,Cc.data_ptr(),N,prec,None)
+            torch.cuda.synchronize()
+            e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20): L.ovm_op_gemm(ah.data_ptr(),al.data_ptr(),K,wh.data_ptr(),wl.data_ptr(),M,N,K,None,0,Cc.data_ptr(),N,prec,None)
+            e1.record(); torch.cuda.synchronize()
+            ms=e0.elapsed_time(e1)/20
+            fl=2.0*M*N*K
+            print(f"N={N} K={K} prec={prec} bm={bm}: {ms*1e3:.1f} us  alg {fl/ms/1e9:.0f} TF  exec {fl*prec/ms/1e9:.0f} TF")
+    if (N,K)==(3072,1024):
+        ref=(A.double()@W.double().T).float()
+        print("check", ((Cc-ref).abs().max()/ref.abs().max()).item())

@@ -32,7 +32,7 @@ def _split(x):
 def test_split_f16_roundtrip(device):
     x = torch.randn(10007, device=device) * 3
     hi, lo = _split(x)
-    rec = hi.float() + lo.float() / 2048.0
+    rec = hi.float() + lo.float()
     assert rel_err(rec, x) < 1e-6
     assert torch.equal(hi, x.half())
 
@@ -55,7 +55,8 @@ def test_gemm_store(device, M, N, K, precision):
     assert rc == 0
     torch.cuda.synchronize()
     ref = torch.relu(A.double() @ W.double().T + bias.double()).float()
-    tol = 2e-6 if precision == 3 else 3e-3
+    # f16x3 leaves fp32 accumulation noise ~ sqrt(K) * 2^-24 (as any fp32 GEMM); f16 leaves operand rounding 2^-11
+    tol = max(2e-6, 3e-8 * math.sqrt(K)) if precision == 3 else 3e-3
     assert_close(Cout[:, :N], ref, tol, f"gemm {M}x{N}x{K} p{precision}")
     assert torch.all(Cout[:, N:] == 7.0), "GEMM wrote outside its N range"
 
