@@ -559,7 +559,7 @@ int ovm_backbone_forward(OvmHandle* h, const OvmImage* images, int32_t B, const 
     {
       GemmParams p = gp_base(h->HN, D, y.qkv, M);
       p.Qhi = h->Q.hi; p.Qlo = h->Q.lo; p.Khi = h->Kx.hi; p.Klo = h->Kx.lo; p.Vhi = h->Vt.hi; p.Vlo = h->Vt.lo;
-      p.T = T; p.Tpad = h->Tpad; p.heads = c.heads; p.qscale = 0.125f;
+      p.T = T; p.Tpad = h->Tpad; p.heads = c.heads; p.qscale = kQScale;
       KCHECK(h, gemm(h, p, EPI_QKV, A_ROWMAJOR, s, OVM_PROF_QKV));
     }
     {

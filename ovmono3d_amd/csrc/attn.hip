@@ -1,6 +1,6 @@
 // Fused (flash-style) multi-head attention for the ViT blocks, head dim 64, gfx950.
 //
-//   softmax(q k^T) v with q pre-scaled by dh^-0.5 in the QKV epilogue (dinov2 Attention.forward as the
+//   softmax(q k^T) v with q pre-scaled by dh^-0.5 * log2(e) in the QKV epilogue (probabilities = exp2) (dinov2 Attention.forward as the
 //   reference reaches it at dino.py:89-90; the xFormers path of nohup.out:696-701 computes the same).
 //
 // Work split: one workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries.
@@ -19,14 +19,40 @@ namespace ovm {
 __device__ __forceinline__ int swz128(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
 template <int NPASS>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
+__device__ __forceinline__ void attn_tail_body(const AttnParams& p, int tb, char* smem);
+
+// 8 fp32 -> fp16 conversions (round-to-nearest, subnormal results kept) in one asm statement: one hazard
+// pad for the lot (see cvt_f16_rn in common.hpp for why these are not left to the compiler).
+__device__ __forceinline__ half8 cvt8_f16_rn(const float* x) {
+  uint32_t r0, r1, r2, r3, r4, r5, r6, r7;
+  asm volatile("s_nop 1\n\tv_cvt_f16_f32 %0, %8\n\tv_cvt_f16_f32 %1, %9\n\tv_cvt_f16_f32 %2, %10\n\tv_cvt_f16_f32 %3, %11\n\t"
+               "v_cvt_f16_f32 %4, %12\n\tv_cvt_f16_f32 %5, %13\n\tv_cvt_f16_f32 %6, %14\n\tv_cvt_f16_f32 %7, %15"
+               : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+               : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+  half8 h;
+  h[0] = __builtin_bit_cast(half_t, (uint16_t)r0); h[1] = __builtin_bit_cast(half_t, (uint16_t)r1);
+  h[2] = __builtin_bit_cast(half_t, (uint16_t)r2); h[3] = __builtin_bit_cast(half_t, (uint16_t)r3);
+  h[4] = __builtin_bit_cast(half_t, (uint16_t)r4); h[5] = __builtin_bit_cast(half_t, (uint16_t)r5);
+  h[6] = __builtin_bit_cast(half_t, (uint16_t)r6); h[7] = __builtin_bit_cast(half_t, (uint16_t)r7);
+  return h;
+}
+
+// Software-pipelined over key tiles inside each wave: iteration t issues the S^T MFMAs of tile t+1, the
+// softmax VALU work of tile t and the PV MFMAs of tile t as one basic block, so matrix and vector pipes
+// overlap without relying on a partner wave. K tiles therefore run one tile ahead of V tiles (two 2-slot
+// LDS rings with a phase offset). Scores are in log2 units (Q is pre-scaled by dh^-0.5 * log2 e), so the
+// probabilities are a bare v_exp_f32.
+template <int NPASS>
+__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x >= p.main_blocks) { attn_tail_body<NPASS>(p, (int)blockIdx.x - p.main_blocks, smem); return; }
   constexpr int PART = 64 * 128;                       // 64 rows x 128 B
-  constexpr int NPART = (NPASS == 3) ? 4 : 2;          // Khi, Vhi, (Klo, Vlo)
-  constexpr int STAGE = PART * NPART;
+  constexpr int SLOT = PART * ((NPASS == 3) ? 2 : 1);  // hi (+ lo)
+  char* const Kring = smem;                            // 2 slots
+  char* const Vring = smem + 2 * SLOT;                 // 2 slots
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nqb = (p.Tq + 127) >> 7;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bid = xcd_remap(blockIdx.x, p.main_blocks);
   const int bh = bid / nqb, qb = bid - bh * nqb;
   const int b = bh / p.heads, head = bh - b * p.heads;
   const int T = p.T;
@@ -34,7 +60,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   const size_t v_base = (size_t)bh * 64 * p.Tpad;
   const int h = lane >> 5, r = lane & 31;
 
-  // ---- Q^T fragments from HBM (B operand: lane holds Q[q][16s + 8h + j]) ----
   int q = qb * 128 + wave * 32 + r;
   const bool q_ok = q < p.Tq;
   if (!q_ok) q = T - 1;
@@ -45,24 +70,50 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     if (NPASS == 3) ql[s] = *(const half8*)(p.Qlo + qk_base + (size_t)q * 64 + 16 * s + 8 * h);
   }
 
-  // ---- DMA plan: per part 8 wave-instructions (8 rows x 128 B each); this wave issues 2 per part ----
-  auto stage = [&](int buf, int it) {
-    char* base = smem + buf * STAGE;
+  // DMA plan: a part is 8 wave-instructions of 8 rows x 128 B; each wave issues 2 of them per part
+  const int drow0 = wave * 8 + (lane >> 3), drow1 = drow0 + 32;
+  const int dch0 = swz128(drow0, lane & 7) * 8, dch1 = swz128(drow1, lane & 7) * 8;
+  auto stageK = [&](int slot, int it) {
+    char* base = Kring + slot * SLOT;
     const int k0 = it * 64;
+    int key0 = k0 + drow0; if (key0 > T - 1) key0 = T - 1;
+    int key1 = k0 + drow1; if (key1 > T - 1) key1 = T - 1;
+    const size_t o0 = qk_base + (size_t)key0 * 64 + dch0, o1 = qk_base + (size_t)key1 * 64 + dch1;
+    glds16(p.Khi + o0, base + wave * 1024);
+    glds16(p.Khi + o1, base + (wave + 4) * 1024);
+    if (NPASS == 3) {
+      glds16(p.Klo + o0, base + PART + wave * 1024);
+      glds16(p.Klo + o1, base + PART + (wave + 4) * 1024);
+    }
+  };
+  auto stageV = [&](int slot, int it) {
+    char* base = Vring + slot * SLOT;
+    const int k0 = it * 64;
+    const size_t o0 = v_base + (size_t)drow0 * p.Tpad + k0 + dch0, o1 = v_base + (size_t)drow1 * p.Tpad + k0 + dch1;
+    glds16(p.Vhi + o0, base + wave * 1024);
+    glds16(p.Vhi + o1, base + (wave + 4) * 1024);
+    if (NPASS == 3) {
+      glds16(p.Vlo + o0, base + PART + wave * 1024);
+      glds16(p.Vlo + o1, base + PART + (wave + 4) * 1024);
+    }
+  };
+  // S^T tile pair (64 keys x 32 queries) from a K slot
+  auto qk = [&](const char* kb, f32x16* s) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int instr = wave + 4 * t;
-      const int row = instr * 8 + (lane >> 3);
-      const int chunk = swz128(row, lane & 7);
-      int key = k0 + row; if (key > T - 1) key = T - 1;
-      const size_t ko = qk_base + (size_t)key * 64 + chunk * 8;
-      const size_t vo = v_base + (size_t)row * p.Tpad + k0 + chunk * 8;
-      char* dst = base + instr * 1024;
-      glds16(p.Khi + ko, dst);
-      glds16(p.Vhi + vo, dst + PART);
-      if (NPASS == 3) {
-        glds16(p.Klo + ko, dst + 2 * PART);
-        glds16(p.Vlo + vo, dst + 3 * PART);
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[i][e] = 0.f;
+      const int row = 32 * i + r;
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const int off = row * 128 + swz128(row, 2 * st + h) * 16;
+        const half8 kh = *(const half8*)(kb + off);
+        if (NPASS == 3) {
+          const half8 kl = *(const half8*)(kb + PART + off);
+          s[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[st], s[i], 0, 0, 0);
+          s[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[st], s[i], 0, 0, 0);
+        }
+        s[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[st], s[i], 0, 0, 0);
       }
     }
   };
@@ -75,72 +126,71 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
   float m_run = -1e30f, l_run = 0.f;
 
   const int nt = (T + 63) >> 6;
-  stage(0, 0);
+  stageK(0, 0);
+  stageV(0, 0);
+  if (nt > 1) stageK(1, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  int cur = 0;
-  for (int it = 0; it < nt; ++it) {
-    if (it + 1 < nt) stage(cur ^ 1, it + 1);
-    const char* base = smem + cur * STAGE;
+  f32x16 sc[2], sn[2];
+  qk(Kring, sc);
+  __syncthreads();                                     // K slot 0 is free for tile 2 from here on
 
-    // ---- S^T = K Q^T : two 32-key tiles ----
-    f32x16 s0[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s0[i][e] = 0.f;
-      const int row = 32 * i + r;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int off = row * 128 + swz128(row, 2 * s + h) * 16;
-        const half8 kh = *(const half8*)(base + off);
-        if (NPASS == 3) {
-          const half8 kl = *(const half8*)(base + 2 * PART + off);
-          s0[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], s0[i], 0, 0, 0);
-          s0[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], s0[i], 0, 0, 0);
-        }
-        s0[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], s0[i], 0, 0, 0);
-      }
-    }
-    // ---- online softmax over the 64 keys of this tile (keys >= T masked) ----
+  for (int it = 0; it < nt; ++it) {
+    if (it + 2 < nt) stageK(it & 1, it + 2);
+    if (it + 1 < nt) stageV((it + 1) & 1, it + 1);
+    // ---- next tile's scores (matrix pipe) ... ----
+    qk(Kring + ((it + 1) & 1) * SLOT, sn);             // past the last tile this reads a stale slot; result unused
+    // ---- ... overlapped with this tile's online softmax (vector pipe) ----
     const int kbase = it * 64;
-    const bool tail = (kbase + 64 > T);
+    if (kbase + 64 > T) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = kbase + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (key >= T) sc[i][e] = -1e30f;
+        }
+    }
     float mx = -1e30f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float v = s0[i][e];
-        if (tail) {
-          const int key = kbase + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (key >= T) v = -1e30f;
-        }
-        s0[i][e] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sc[i][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);
+    const bool grew = m_new > m_run;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     float psum = 0.f;
     half8 ph[2][2], pl[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float pv = __expf(s0[i][e] - m_new);
-        psum += pv;
-        half_t hh, ll; split_f16(pv, hh, ll);
-        ph[i][e >> 3][e & 7] = hh;
-        if (NPASS == 3) pl[i][e >> 3][e & 7] = ll;
+      for (int sp = 0; sp < 2; ++sp) {
+        float pv[8], pd[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          pv[e] = __builtin_amdgcn_exp2f(sc[i][8 * sp + e] - m_new);
+          psum += pv[e];
+        }
+        // hi may come from the packed convert: if it flushes a subnormal to zero the lo part below carries it
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ph[i][sp][e] = (half_t)pv[e];
+        if (NPASS == 3) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pd[e] = pv[e] - (float)ph[i][sp][e];
+          pl[i][sp] = cvt8_f16_rn(pd);
+        }
       }
     l_run = l_run * alpha + psum;
+    if (__any(grew)) {                                 // rescale only when some query's running max moved
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) o0[t][e] *= alpha;
-
+        for (int e = 0; e < 16; ++e) o0[t][e] *= alpha;
+    }
     // ---- O^T += V^T P^T ----
+    const char* vb = Vring + (it & 1) * SLOT;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int row = 32 * t + r;
@@ -149,9 +199,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int sp = 0; sp < 2; ++sp) {
           const int off = row * 128 + swz128(row, 4 * i + 2 * sp + h) * 16;
-          const half8 vh = *(const half8*)(base + PART + off);
+          const half8 vh = *(const half8*)(vb + off);
           if (NPASS == 3) {
-            const half8 vl = *(const half8*)(base + 3 * PART + off);
+            const half8 vl = *(const half8*)(vb + PART + off);
             o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[i][sp], o0[t], 0, 0, 0);
             o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[i][sp], o0[t], 0, 0, 0);
           }
@@ -160,7 +210,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    cur ^= 1;
+    sc[0] = sn[0];
+    sc[1] = sn[1];
   }
 
   // ---- normalise and store: lane holds query q, dh = 32t + 8g + 4h + {0..3} ----
@@ -190,44 +241,56 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 // here instead: one workgroup per (query, batch*head), scores and probabilities in LDS, fp32 FMAs on the
 // reconstructed (hi + lo) operands.
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Tail query rows. T = 4097 leaves ONE query past 32 blocks of 128; as a 33rd block per head it would
+// add a second, nearly empty round of workgroups. Up to 8 leftover queries per (batch, head) are handled by
+// extra workgroups of the same launch instead: scores and probabilities in LDS, fp32 FMAs on the
+// reconstructed (hi + lo) operands, all global reads coalesced along the contiguous axis.
+// ---------------------------------------------------------------------------------------------
 template <int NPASS>
-__global__ __launch_bounds__(256) void attn_tail_kernel(const AttnParams p, int q_begin) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void attn_tail_body(const AttnParams& p, int tb, char* smem) {
   float* sc = (float*)smem;                       // [Tpad] scores -> probabilities, in V^T's permuted token order
-  __shared__ float red[8];
-  __shared__ float part[4][64];
+  float* red = sc + p.Tpad;                       // [8]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bh = blockIdx.x, q = q_begin + blockIdx.y;
+  const int ntail = p.T - p.Tq;
+  const int bh = tb / ntail, q = p.Tq + (tb - bh * ntail);
   const int b = bh / p.heads, head = bh - b * p.heads;
   const int T = p.T, Tpad = p.Tpad;
   const size_t qk_base = (size_t)bh * T * 64;
   const size_t v_base = (size_t)bh * 64 * Tpad;
-  float qv[64];
+  // lane l of a wave holds q[8*(l&7) .. +8): 8 lanes cover one key row (128 B contiguous), 8 keys per wave pass
+  float qv[8];
+  {
+    const half8 qh = *(const half8*)(p.Qhi + qk_base + (size_t)q * 64 + 8 * (lane & 7));
 #pragma unroll
-  for (int d = 0; d < 64; ++d) {
-    qv[d] = (float)p.Qhi[qk_base + (size_t)q * 64 + d];
-    if (NPASS == 3) qv[d] += (float)p.Qlo[qk_base + (size_t)q * 64 + d];
+    for (int j = 0; j < 8; ++j) qv[j] = (float)qh[j];
+    if (NPASS == 3) {
+      const half8 ql = *(const half8*)(p.Qlo + qk_base + (size_t)q * 64 + 8 * (lane & 7));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qv[j] += (float)ql[j];
+    }
   }
   float mx = -1e30f;
-  for (int t = tid; t < Tpad; t += 256) {
-    float s = -1e30f;
+  for (int t0 = wave * 8; t0 < Tpad; t0 += 32) {
+    const int t = t0 + (lane >> 3);
+    float s = 0.f;
     if (t < T) {
-      s = 0.f;
+      const half8 kh = *(const half8*)(p.Khi + qk_base + (size_t)t * 64 + 8 * (lane & 7));
+      half8 kl;
+      if (NPASS == 3) kl = *(const half8*)(p.Klo + qk_base + (size_t)t * 64 + 8 * (lane & 7));
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const half8 kh = *(const half8*)(p.Khi + qk_base + (size_t)t * 64 + c * 8);
-        half8 kl;
-        if (NPASS == 3) kl = *(const half8*)(p.Klo + qk_base + (size_t)t * 64 + c * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float kv = (float)kh[j];
-          if (NPASS == 3) kv += (float)kl[j];
-          s = fmaf(qv[c * 8 + j], kv, s);
-        }
+      for (int j = 0; j < 8; ++j) {
+        float kv = (float)kh[j];
+        if (NPASS == 3) kv += (float)kl[j];
+        s = fmaf(qv[j], kv, s);
       }
     }
-    const int tp = (t & ~15) | (t & 3) | ((t & 4) << 1) | ((t & 8) >> 1);
-    sc[tp] = s;
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if (t >= T) s = -1e30f;
+    if ((lane & 7) == 0) {
+      const int tp = (t & ~15) | (t & 3) | ((t & 4) << 1) | ((t & 8) >> 1);
+      sc[tp] = s;
+    }
     mx = fmaxf(mx, s);
   }
   mx = wave_max(mx);
@@ -236,7 +299,7 @@ __global__ __launch_bounds__(256) void attn_tail_kernel(const AttnParams p, int 
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float sum = 0.f;
   for (int t = tid; t < Tpad; t += 256) {
-    const float e = __expf(sc[t] - mx);          // masked slots hold -1e30 -> 0
+    const float e = __builtin_amdgcn_exp2f(sc[t] - mx);   // scores are in log2 units; masked slots hold -1e30 -> 0
     sc[t] = e;
     sum += e;
   }
@@ -244,32 +307,28 @@ __global__ __launch_bounds__(256) void attn_tail_kernel(const AttnParams p, int 
   if (lane == 0) red[4 + wave] = sum;
   __syncthreads();
   const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
-  // O[d] = sum_t p[t] V[t][d]; wave w covers a quarter of the (permuted) token axis, lane = d
-  const int d = lane;
-  const int q4 = Tpad / 4;                        // Tpad % 64 == 0
-  float o = 0.f;
-  const half_t* vh = p.Vhi + v_base + (size_t)d * Tpad + wave * q4;
-  const half_t* vl = (NPASS == 3) ? p.Vlo + v_base + (size_t)d * Tpad + wave * q4 : nullptr;
-  const float* pr = sc + wave * q4;
-  for (int j = 0; j < q4; j += 8) {
-    const half8 h8 = *(const half8*)(vh + j);
-    half8 l8;
-    if (NPASS == 3) l8 = *(const half8*)(vl + j);
+  // O[d] = sum_t p[t] V^T[d][t]: wave w owns d in [16w, 16w+16), lanes run along the token axis (coalesced)
+  for (int dd = 0; dd < 16; ++dd) {
+    const int d = wave * 16 + dd;
+    float o = 0.f;
+    for (int j = lane * 8; j < Tpad; j += 512) {
+      const half8 h8 = *(const half8*)(p.Vhi + v_base + (size_t)d * Tpad + j);
+      half8 l8;
+      if (NPASS == 3) l8 = *(const half8*)(p.Vlo + v_base + (size_t)d * Tpad + j);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = (float)h8[e];
-      if (NPASS == 3) v += (float)l8[e];
-      o = fmaf(pr[j + e], v, o);
+      for (int e = 0; e < 8; ++e) {
+        float v = (float)h8[e];
+        if (NPASS == 3) v += (float)l8[e];
+        o = fmaf(sc[j + e], v, o);
+      }
     }
-  }
-  part[wave][d] = o;
-  __syncthreads();
-  if (wave == 0) {
-    const float r = (part[0][d] + part[1][d] + part[2][d] + part[3][d]) * inv;
-    half_t hh, ll; split_f16(r, hh, ll);
-    const size_t oo = ((size_t)b * T + q) * p.ldo + head * 64 + d;
-    p.Ohi[oo] = hh;
-    if (p.Olo) p.Olo[oo] = ll;
+    o = wave_sum(o);
+    if (lane == 0) {
+      half_t hh, ll; split_f16(o * inv, hh, ll);
+      const size_t oo = ((size_t)b * T + q) * p.ldo + head * 64 + d;
+      p.Ohi[oo] = hh;
+      if (p.Olo) p.Olo[oo] = ll;
+    }
   }
 }
 
@@ -282,16 +341,15 @@ int launch_attention(const AttnParams& p, int npass, hipStream_t s) {
   if (npass == 3 && (!p.Qlo || !p.Klo || !p.Vlo)) return OVM_ERR_INVALID;
   AttnParams pm = p;
   const int tail = p.T % 128;
-  if (g_attn_tail && tail > 0 && tail <= 8 && p.T > 128 && p.Tpad * 4 <= 60000) {
-    const dim3 tg(p.heads * p.B, tail);
-    if (npass == 3) hipLaunchKernelGGL(attn_tail_kernel<3>, tg, dim3(256), p.Tpad * 4, s, p, p.T - tail);
-    else hipLaunchKernelGGL(attn_tail_kernel<1>, tg, dim3(256), p.Tpad * 4, s, p, p.T - tail);
-    pm.Tq = p.T - tail;
-  } else {
-    pm.Tq = p.T;
+  int tail_blocks = 0;
+  pm.Tq = p.T;
+  if (g_attn_tail && tail > 0 && tail <= 8 && p.T > 128 && (p.Tpad + 8) * 4 <= 2 * 2 * 64 * 128) {
+    pm.Tq = p.T - tail;                            // leftover queries ride along as extra workgroups
+    tail_blocks = tail * p.heads * p.B;
   }
   const int nqb = (pm.Tq + 127) / 128;
-  const dim3 grid(nqb * p.heads * p.B), block(256);
+  pm.main_blocks = nqb * p.heads * p.B;
+  const dim3 grid(pm.main_blocks + tail_blocks), block(256);
   if (npass == 3) hipLaunchKernelGGL(attn_kernel<3>, grid, block, 2 * 4 * 64 * 128, s, pm);
   else hipLaunchKernelGGL(attn_kernel<1>, grid, block, 2 * 2 * 64 * 128, s, pm);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;

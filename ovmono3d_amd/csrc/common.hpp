@@ -18,6 +18,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // One-pass mode (precision "f16") uses hi only; three-pass mode ("f16x3") accumulates
 //   acc += Ah*Wh + Al*Wh + Ah*Wl          (the Al*Wl term, ~2^-22 relative, is dropped)
 // into ONE fp32 accumulator, so the split costs MFMA issue slots but no extra registers.
+// Q is stored pre-multiplied by dh^-0.5 * log2(e) (dh = 64) so that attention probabilities are exp2(s - m).
+constexpr float kQScale = 0.125f * 1.44269504088896340736f;
 constexpr float kLoScale = 1.0f;
 constexpr float kLoInv = 1.0f;
 

@@ -11,9 +11,21 @@ void gemm_set_tail_rows(int on) { g_tail_rows = on; }
 template <int NPASS, int BK, int BM, int EPI, int AMODE>
 static int launch_one(const GemmParams& p, hipStream_t s) {
   constexpr int smem = 2 * (BM + 128) * BK * 2 * ((NPASS == 3) ? 2 : 1);
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int tiles_n = (p.N + 127) / 128;
   if (p.K % BK != 0) return OVM_ERR_SHAPE;
+  GemmParams q = p;
+  q.M_total = p.M; q.tail_begin = p.M; q.main_tiles = 0;
+  int tail_blocks = 0;
+  const int tail = p.M % 128;
+  if (g_tail_rows && tail > 0 && tail <= 8 && p.M > 128 && p.K % 64 == 0) {
+    // leftover rows (the cls token of the 4097-token canvas) ride along as extra dot-product workgroups
+    q.tail_begin = p.M - tail;
+    q.M = q.tail_begin;
+    const int waves = BM / 32;
+    tail_blocks = tail * ((p.N + 4 * waves - 1) / (4 * waves));
+  }
+  const int tiles_m = (q.M + BM - 1) / BM;
+  const int tiles_n = (p.N + 127) / 128;
+  q.main_tiles = tiles_m * tiles_n;
   static bool attr_set = false;
   if (!attr_set) {
     if (smem > 65536 &&
@@ -21,7 +33,7 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
       return OVM_ERR_HIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<NPASS, BK, BM, EPI, AMODE>), dim3(tiles_m * tiles_n), dim3(BM * 2), smem, s, p);
+  hipLaunchKernelGGL((gemm_kernel<NPASS, BK, BM, EPI, AMODE>), dim3(q.main_tiles + tail_blocks), dim3(BM * 2), smem, s, q);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 
@@ -34,18 +46,8 @@ static int pick_bm(const GemmParams& p) {
 }
 
 template <int EPI, int AMODE>
-static int launch_prec(const GemmParams& p0, int npass, hipStream_t s) {
-  if (p0.M <= 0 || p0.N <= 0) return OVM_OK;
-  GemmParams p = p0;
-  const int tail = p0.M % 128;
-  if (g_tail_rows && tail > 0 && tail <= 8 && p0.M > 128 && p0.K % 64 == 0) {
-    // leftover rows (e.g. the cls token of the 4097-token canvas) go to the dot-product kernel
-    const int m_begin = p0.M - tail;
-    const dim3 grid((p0.N + 15) / 16, tail);
-    if (npass == 3) hipLaunchKernelGGL((gemm_tail_kernel<3, EPI, AMODE>), grid, dim3(256), 0, s, p0, m_begin);
-    else hipLaunchKernelGGL((gemm_tail_kernel<1, EPI, AMODE>), grid, dim3(256), 0, s, p0, m_begin);
-    p.M = m_begin;
-  }
+static int launch_prec(const GemmParams& p, int npass, hipStream_t s) {
+  if (p.M <= 0 || p.N <= 0) return OVM_OK;
   const int bm = pick_bm(p);
   if (npass == 3) return bm == 256 ? launch_one<3, 32, 256, EPI, AMODE>(p, s) : launch_one<3, 32, 128, EPI, AMODE>(p, s);
   return bm == 256 ? launch_one<1, 64, 256, EPI, AMODE>(p, s) : launch_one<1, 64, 128, EPI, AMODE>(p, s);

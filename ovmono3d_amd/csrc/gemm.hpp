@@ -43,6 +43,9 @@ struct GemmParams {
   const float* pos; int G2;
   // EPI_CONVT: m = (b, i, j) over GxG, n = (a*2 + bb)*Cout + co -> NHWC [B][2G][2G][Cout]
   int G, Cout;
+  // set by the launcher: workgroups [0, main_tiles) run MFMA tiles over rows [0, tail_begin); workgroups beyond
+  // them compute the leftover rows [tail_begin, M) with the dot-product body (see gemm_tail_body)
+  int main_tiles, tail_begin, M_total;
 };
 
 template <int BK> __device__ __forceinline__ int swz_slot(int row, int chunk);
@@ -167,8 +170,12 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32
   }
 }
 
+template <int NPASS, int EPI, int AMODE>
+__device__ __forceinline__ void gemm_tail_body(const GemmParams& p, int tb);
+
 template <int NPASS, int BK, int BM, int EPI, int AMODE>
 __global__ __launch_bounds__(BM * 2) void gemm_kernel(const GemmParams p) {
+  if ((int)blockIdx.x >= p.main_tiles) { gemm_tail_body<NPASS, EPI, AMODE>(p, (int)blockIdx.x - p.main_tiles); return; }
   // Block tile BM x 128 (BM = 128: 4 waves, BM = 256: 8 waves); every wave owns a 64 x 64 sub-tile.
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = BM / 32;                     // waves per block
@@ -184,10 +191,10 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const GemmParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_m = (p.M + BM - 1) / BM;
-  const int tiles_n = gridDim.x / tiles_m;
+  const int tiles_n = p.main_tiles / tiles_m;
   // XCD-aware remap, then grouped ordering (8 row-tiles per group) so the tiles that run concurrently on one
   // XCD form a compact 2-D patch: each A / W k-slice is fetched into that XCD's L2 once and reused.
-  int pid = xcd_remap(blockIdx.x, gridDim.x);
+  int pid = xcd_remap(blockIdx.x, p.main_tiles);
   constexpr int GROUP_M = 8;
   const int in_group = GROUP_M * tiles_n;
   const int gid = pid / in_group;
@@ -305,11 +312,15 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const GemmParams p) {
 // (fp32 FMA on the reconstructed hi+lo operands, same epilogues).
 // ---------------------------------------------------------------------------------------------
 template <int NPASS, int EPI, int AMODE>
-__global__ __launch_bounds__(256) void gemm_tail_kernel(const GemmParams p, int m_begin) {
+__device__ __forceinline__ void gemm_tail_body(const GemmParams& p, int tb) {
+  // tb = tail workgroup index; every wave computes 4 consecutive columns of one leftover row
   const int lane = threadIdx.x & 63;
-  const int n = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
-  const int m = m_begin + blockIdx.y;
-  if (n >= p.N || m >= p.M) return;
+  const int waves = blockDim.x >> 6;
+  const int groups_per_row = (p.N + 4 * waves - 1) / (4 * waves);
+  const int row = tb / groups_per_row;
+  const int n = ((tb - row * groups_per_row) * waves + (threadIdx.x >> 6)) * 4;
+  const int m = p.tail_begin + row;
+  if (n >= p.N || m >= p.M_total) return;
   const uint32_t arow = a_row_offset<AMODE>(p, m);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int k0 = lane * 8; k0 < p.K; k0 += 512) {
@@ -342,7 +353,10 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(const GemmParams p, int 
   f32x4 v;
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = wave_sum(acc[r]);
-  if (lane == 0) epilogue4<EPI>(p, m, n, v);
+  if (lane == 0) {
+    GemmParams q = p; q.M = p.M_total;
+    epilogue4<EPI>(q, m, n, v);
+  }
 }
 
 // Host launcher (defined in gemm.hip). npass in {1,3}.

@@ -21,7 +21,7 @@ struct AttnParams {
   const half_t *Qhi, *Qlo, *Khi, *Klo, *Vhi, *Vlo;   // Q,K [B][h][T][64]; V^T [B][h][64][Tpad] (permuted tokens)
   half_t *Ohi, *Olo; int ldo;                        // out rows b*T + t, column head*64 + d
   int B, heads, T, Tpad;
-  int Tq;                                            // query rows covered by the tiled kernel (set by the launcher)
+  int Tq, main_blocks;                               // set by the launcher: queries / workgroups of the tiled part
 };
 
 struct RoiParams {

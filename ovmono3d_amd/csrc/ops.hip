@@ -27,7 +27,7 @@ __global__ void qkv_layout_kernel(const float* __restrict__ qkv, int B, int T, i
   const int n = (int)(i % (3 * D)); const int64_t m = i / (3 * D);
   const int b = (int)(m / T), t = (int)(m - (int64_t)b * T);
   const int which = n / D, f = n - which * D, head = f >> 6, d = f & 63;
-  float v = qkv[i]; if (which == 0) v *= 0.125f;
+  float v = qkv[i]; if (which == 0) v *= kQScale;
   half_t h, l; split_f16(v, h, l);
   if (which < 2) {
     const size_t o = ((size_t)(b * heads + head) * T + t) * 64 + d;

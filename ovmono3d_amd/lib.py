@@ -96,6 +96,10 @@ def load() -> C.CDLL:
     for name in EXPORTS:
         if name not in ("ovm_last_error", "ovm_version", "ovm_debug_copy"):
             getattr(lib, name).restype = i32
+    # experiment knobs, e.g. OVM_TUNE="gemm_bm=256,attn_tail=0"
+    for kv in filter(None, os.environ.get("OVM_TUNE", "").split(",")):
+        k, _, v = kv.partition("=")
+        lib.ovm_tune_set(k.strip().encode(), int(v))
     _lib = lib
     return lib
 
