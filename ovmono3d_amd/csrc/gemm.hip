@@ -5,12 +5,14 @@ namespace ovm {
 
 static int g_force_bm = 0;
 static int g_tail_rows = 1;
+static int g_force_stages = 0;
+void gemm_set_stages(int n) { g_force_stages = n; }
 void gemm_set_force_bm(int bm) { g_force_bm = bm; }
 void gemm_set_tail_rows(int on) { g_tail_rows = on; }
 
-template <int NPASS, int BK, int BM, int EPI, int AMODE>
+template <int NPASS, int BK, int BM, int NSTAGE, int EPI, int AMODE>
 static int launch_one(const GemmParams& p, hipStream_t s) {
-  constexpr int smem = 2 * (BM + 128) * BK * 2 * ((NPASS == 3) ? 2 : 1);
+  constexpr int smem = NSTAGE * (BM + 128) * BK * 2 * ((NPASS == 3) ? 2 : 1);
   if (p.K % BK != 0) return OVM_ERR_SHAPE;
   GemmParams q = p;
   q.M_total = p.M; q.tail_begin = p.M; q.main_tiles = 0;
@@ -29,28 +31,33 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     if (smem > 65536 &&
-        hipFuncSetAttribute((const void*)gemm_kernel<NPASS, BK, BM, EPI, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        hipFuncSetAttribute((const void*)gemm_kernel<NPASS, BK, BM, NSTAGE, EPI, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return OVM_ERR_HIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<NPASS, BK, BM, EPI, AMODE>), dim3(q.main_tiles + tail_blocks), dim3(BM * 2), smem, s, q);
+  hipLaunchKernelGGL((gemm_kernel<NPASS, BK, BM, NSTAGE, EPI, AMODE>), dim3(q.main_tiles + tail_blocks), dim3(BM * 2), smem, s, q);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 
-// Tile height: 256 rows halve the W-panel traffic per FLOP; 128 rows give twice the workgroups. Use the tall
-// tile when it still yields at least ~one full wave of workgroups over the 256 CUs.
+// Tile height. Measured on MI355X at the ViT-L shapes (M = 4097; N, K in {1024, 3072, 4096}; profiles/r01):
+// 128 rows with two LDS stages (2-3 workgroups per CU) beats 256 rows and the 3-stage ring everywhere, so that
+// is the default; the other variants stay selectable for tuning (ovm_tune_set "gemm_bm" / "gemm_stages").
 static int pick_bm(const GemmParams& p) {
-  if (g_force_bm == 128 || g_force_bm == 256) return g_force_bm;
-  const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
-  return tiles256 >= 224 ? 256 : 128;
+  (void)p;
+  return g_force_bm == 256 ? 256 : 128;
 }
 
 template <int EPI, int AMODE>
 static int launch_prec(const GemmParams& p, int npass, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return OVM_OK;
   const int bm = pick_bm(p);
-  if (npass == 3) return bm == 256 ? launch_one<3, 32, 256, EPI, AMODE>(p, s) : launch_one<3, 32, 128, EPI, AMODE>(p, s);
-  return bm == 256 ? launch_one<1, 64, 256, EPI, AMODE>(p, s) : launch_one<1, 64, 128, EPI, AMODE>(p, s);
+  const int st = g_force_stages ? g_force_stages : 2;
+  if (npass == 3) {
+    if (bm == 256) return st == 3 ? launch_one<3, 32, 256, 3, EPI, AMODE>(p, s) : launch_one<3, 32, 256, 2, EPI, AMODE>(p, s);
+    return st == 3 ? launch_one<3, 32, 128, 3, EPI, AMODE>(p, s) : launch_one<3, 32, 128, 2, EPI, AMODE>(p, s);
+  }
+  if (bm == 256) return st == 3 ? launch_one<1, 64, 256, 3, EPI, AMODE>(p, s) : launch_one<1, 64, 256, 2, EPI, AMODE>(p, s);
+  return st == 3 ? launch_one<1, 64, 128, 3, EPI, AMODE>(p, s) : launch_one<1, 64, 128, 2, EPI, AMODE>(p, s);
 }
 
 int launch_gemm(const GemmParams& p, int npass, int epi, int amode, hipStream_t s) {

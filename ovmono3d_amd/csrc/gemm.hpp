@@ -173,7 +173,7 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32
 template <int NPASS, int EPI, int AMODE>
 __device__ __forceinline__ void gemm_tail_body(const GemmParams& p, int tb);
 
-template <int NPASS, int BK, int BM, int EPI, int AMODE>
+template <int NPASS, int BK, int BM, int NSTAGE, int EPI, int AMODE>
 __global__ __launch_bounds__(BM * 2) void gemm_kernel(const GemmParams p) {
   if ((int)blockIdx.x >= p.main_tiles) { gemm_tail_body<NPASS, EPI, AMODE>(p, (int)blockIdx.x - p.main_tiles); return; }
   // Block tile BM x 128 (BM = 128: 4 waves, BM = 256: 8 waves); every wave owns a 64 x 64 sub-tile.
@@ -250,15 +250,14 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const GemmParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
+  // glds instructions one wave issues per stage (for the counted vmcnt of the 3-stage ring)
+  constexpr int PER_STAGE = (IA + ((NIW >= NW) ? IW : 0)) * ((NPASS == 3) ? 2 : 1);
+  static_assert(NSTAGE == 2 || (NIW % NW == 0 || NIW < NW), "3-stage ring needs a wave-uniform DMA count");
+  // s_waitcnt immediate: vmcnt = N, expcnt / lgkmcnt untouched
+  constexpr int WAIT_ONE_STAGE = (PER_STAGE & 0xF) | (7 << 4) | (15 << 8) | ((PER_STAGE >> 4) << 14);
   const int fr = lane & 15, fq = lane >> 4;
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const char* base = smem + cur * STAGE;
+
+  auto compute = [&](const char* base) {
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
       half8 ah[4], wh[4], al[4], wl[4];
@@ -287,9 +286,37 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const GemmParams p) {
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ni], ah[mi], acc[ni][mi], 0, 0, 0);
         }
     }
+  };
+
+  if (NSTAGE == 2) {
+    stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    cur ^= 1;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+      compute(smem + cur * STAGE);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    // 3-slot ring, two k-tiles in flight: at the end of iteration kt only tile kt+1 must have landed, so the
+    // wait is a counted vmcnt that leaves tile kt+2's DMA outstanding across a raw s_barrier.
+    stage(0, 0);
+    if (nk > 1) { stage(1, 1); __builtin_amdgcn_s_waitcnt(WAIT_ONE_STAGE); } else { __builtin_amdgcn_s_waitcnt(0x0F70 & ~0xF); }
+    __builtin_amdgcn_s_barrier();
+    int cur = 0, nxt2 = 2;
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = (kt + 2 < nk);
+      if (more) stage(nxt2, kt + 2);
+      compute(smem + cur * STAGE);
+      if (more) __builtin_amdgcn_s_waitcnt(WAIT_ONE_STAGE); else __builtin_amdgcn_s_waitcnt(0x0F70 & ~0xF);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      cur = (cur == 2) ? 0 : cur + 1;
+      nxt2 = (nxt2 == 2) ? 0 : nxt2 + 1;
+    }
   }
 
   // ---- epilogue: lane holds (m = m0+wm*64+mi*16+fr, n = n0+wn*64+ni*16+fq*4 .. +3)
@@ -364,5 +391,6 @@ int launch_gemm(const GemmParams& p, int npass, int epi, int amode, hipStream_t 
 // Tile-height override for tuning (0 = heuristic): 128 or 256.
 void gemm_set_force_bm(int bm);
 void gemm_set_tail_rows(int on);
+void gemm_set_stages(int n);
 
 }  // namespace ovm

@@ -154,6 +154,7 @@ int ovm_op_cube_decode(const float* head13, int32_t ld, const float* boxes, cons
 int ovm_tune_set(const char* key, int32_t value) {
   if (!key) return OVM_ERR_INVALID;
   if (!strcmp(key, "gemm_bm")) { gemm_set_force_bm(value); return OVM_OK; }
+  if (!strcmp(key, "gemm_stages")) { gemm_set_stages(value); return OVM_OK; }
   if (!strcmp(key, "gemm_tail")) { gemm_set_tail_rows(value); return OVM_OK; }
   if (!strcmp(key, "attn_tail")) { attn_set_tail_rows(value); return OVM_OK; }
   return OVM_ERR_INVALID;
