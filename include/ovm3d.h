@@ -181,6 +181,16 @@ int ovm_op_cube_decode(const float* head13, int32_t ld, const float* boxes, cons
 int ovm_op_nms(const float* boxes, const float* scores, int32_t n, float thresh, int32_t* keep_idx, int32_t* n_keep,
                ovm_stream_t stream);
 
+/* --- GroundingDINO output glue of ROIHeads3DGDINO (reference roi_heads_gdino.py:186-202,236-263,266-294):
+ * pred_logits [nq][ld] (pre-sigmoid token logits, ld = 256), pred_boxes [nq][4] cxcywh in [0,1] (device);
+ * spans: host int32 [n_phrases][2] = [begin, end) token positions of each category phrase (walked from id 1,
+ * +1 per separator, :277-291). Sigmoid, per-phrase SUM, max / first-argmax, strict `> box_threshold`, * [w,h,w,h],
+ * cxcywh->xyxy, class-agnostic NMS. Outputs (device, capacity nq) in decreasing-score order; n_out device int32.
+ * Synchronises the stream. */
+int ovm_gdino_postprocess(const float* pred_logits, int32_t nq, int32_t ld, const float* pred_boxes, const int32_t* spans,
+                          int32_t n_phrases, int32_t img_h, int32_t img_w, float box_threshold, float nms_threshold,
+                          float* out_boxes, float* out_scores, int32_t* out_classes, int32_t* n_out, ovm_stream_t stream);
+
 /* tuning knob for experiments: key "gemm_bm" = 0 (heuristic) | 128 | 256 */
 int ovm_tune_set(const char* key, int32_t value);
 

@@ -509,10 +509,12 @@ int det2d_forward(const Det2dModel& m, Det2dWorkspace& w, float* boxes, float* s
 // Standalone class-agnostic NMS (op-level entry; also the GroundingDINO glue's NMS, roi_heads_gdino.py:254)
 // ------------------------------------------------------------------------------------------------
 namespace {
-__global__ void single_keys_kernel(const float* __restrict__ scores, int n, int N, unsigned long long* __restrict__ keys) {
+__global__ void single_keys_kernel(const float* __restrict__ scores, const int* __restrict__ valid, int n, int N,
+                                   unsigned long long* __restrict__ keys) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  keys[i] = (i < n) ? (((unsigned long long)(~ord32(scores[i])) << 24) | (unsigned long long)i) : kInvalidKey;
+  const bool ok = (i < n) && (!valid || valid[i]);
+  keys[i] = ok ? (((unsigned long long)(~ord32(scores[i])) << 24) | (unsigned long long)i) : kInvalidKey;
 }
 __global__ void single_gather_kernel(const unsigned long long* __restrict__ keys, const float* __restrict__ boxes, int n, int N,
                                      float* __restrict__ sbox, int* __restrict__ sgroup, int* __restrict__ gse) {
@@ -552,7 +554,8 @@ __global__ __launch_bounds__(1024) void single_emit_kernel(const unsigned long l
 }
 }  // namespace
 
-int launch_nms_single(const float* boxes, const float* scores, int n, float thresh, int* keep_idx, int* n_keep, hipStream_t s) {
+int launch_nms_single(const float* boxes, const float* scores, const int* valid, int n, float thresh, int* keep_idx, int* n_keep,
+                      hipStream_t s) {
   if (n <= 0) return hipMemsetAsync(n_keep, 0, sizeof(int), s) == hipSuccess ? OVM_OK : OVM_ERR_HIP;
   if (n > 4096) return OVM_ERR_CAPACITY;
   const int N = pow2_at_least(n), W = (n + 63) / 64;
@@ -564,7 +567,7 @@ int launch_nms_single(const float* boxes, const float* scores, int n, float thre
     for (void* p : tmp) (void)hipFree(p);
     return r;
   }
-  hipLaunchKernelGGL(single_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, s, scores, n, N, keys);
+  hipLaunchKernelGGL(single_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, s, scores, valid, n, N, keys);
   r = sort_keys(keys, N, 1, s);
   if (!r) {
     hipLaunchKernelGGL(single_gather_kernel, dim3((N + 255) / 256), dim3(256), 0, s, keys, boxes, n, N, sbox, sgroup, gse);
@@ -572,6 +575,70 @@ int launch_nms_single(const float* boxes, const float* scores, int n, float thre
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1, 1), dim3(64), 0, s, sgroup, gse, gse + 1, 1, N, W, mask, keep);
     hipLaunchKernelGGL(single_emit_kernel, dim3(1), dim3(1024), 0, s, keys, keep, n, keep_idx, n_keep);
     if (hipStreamSynchronize(s) != hipSuccess) r = OVM_ERR_HIP;
+  }
+  for (void* p : tmp) (void)hipFree(p);
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroundingDINO output glue (reference cubercnn/modeling/roi_heads/roi_heads_gdino.py:186-202,253,266-294):
+// sigmoid of the token logits, per-phrase SUM over the phrase's token span, max / first-argmax over phrases,
+// strict threshold, cxcywh (normalised) -> xyxy pixels, class-agnostic NMS.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ void gdino_phrase_kernel(const float* __restrict__ logits, int nq, int ld, const float* __restrict__ cxcywh,
+                                    const int* __restrict__ spans, int K, float img_h, float img_w, float thr,
+                                    float* __restrict__ xyxy, float* __restrict__ score, int* __restrict__ cls,
+                                    int* __restrict__ valid) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const float* l = logits + (size_t)q * ld;
+  float best = -INFINITY; int arg = 0;
+  for (int k = 0; k < K; ++k) {
+    float sum = 0.f;
+    for (int t = spans[2 * k]; t < spans[2 * k + 1]; ++t) sum += 1.0f / (1.0f + expf(-l[t]));
+    if (sum > best) { best = sum; arg = k; }          // torch.max returns the first maximal index
+  }
+  const float cx = cxcywh[q * 4] * img_w, cy = cxcywh[q * 4 + 1] * img_h, w = cxcywh[q * 4 + 2] * img_w, h = cxcywh[q * 4 + 3] * img_h;
+  xyxy[q * 4 + 0] = cx - 0.5f * w; xyxy[q * 4 + 1] = cy - 0.5f * h;
+  xyxy[q * 4 + 2] = cx + 0.5f * w; xyxy[q * 4 + 3] = cy + 0.5f * h;
+  score[q] = best; cls[q] = arg;
+  valid[q] = (K > 0 && best > thr) ? 1 : 0;
+}
+__global__ void gdino_gather_kernel(const int* __restrict__ keep_idx, const int* __restrict__ n_keep, const float* __restrict__ xyxy,
+                                    const float* __restrict__ score, const int* __restrict__ cls, float* __restrict__ ob,
+                                    float* __restrict__ os, int* __restrict__ oc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= *n_keep) return;
+  const int q = keep_idx[i];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) ob[i * 4 + c] = xyxy[q * 4 + c];
+  os[i] = score[q]; oc[i] = cls[q];
+}
+}  // namespace
+
+int launch_gdino_post(const float* logits, int nq, int ld, const float* cxcywh, const int* spans, int K, int img_h, int img_w,
+                      float box_thr, float nms_thr, float* out_boxes, float* out_scores, int* out_classes, int* n_out, hipStream_t s) {
+  if (nq == 0) return hipMemsetAsync(n_out, 0, sizeof(int), s) == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+  if (nq < 0 || nq > 4096 || K < 0) return OVM_ERR_CAPACITY;
+  std::vector<void*> tmp;
+  float *xyxy = nullptr, *score = nullptr; int *cls = nullptr, *valid = nullptr, *keep = nullptr, *dsp = nullptr;
+  int r;
+  if ((r = dmalloc(&xyxy, (size_t)nq * 4, &tmp)) || (r = dmalloc(&score, (size_t)nq, &tmp)) || (r = dmalloc(&cls, (size_t)nq, &tmp)) ||
+      (r = dmalloc(&valid, (size_t)nq, &tmp)) || (r = dmalloc(&keep, (size_t)nq, &tmp)) || (r = dmalloc(&dsp, (size_t)(2 * K + 2), &tmp))) {
+    for (void* p : tmp) (void)hipFree(p);
+    return r;
+  }
+  if (K > 0 && hipMemcpyAsync(dsp, spans, sizeof(int) * 2 * K, hipMemcpyHostToDevice, s) != hipSuccess) r = OVM_ERR_HIP;
+  if (!r) {
+    hipLaunchKernelGGL(gdino_phrase_kernel, dim3((nq + 127) / 128), dim3(128), 0, s, logits, nq, ld, cxcywh, dsp, K, (float)img_h,
+                       (float)img_w, box_thr, xyxy, score, cls, valid);
+    r = launch_nms_single(xyxy, score, valid, nq, nms_thr, keep, n_out, s);      // synchronises
+    if (!r) {
+      hipLaunchKernelGGL(gdino_gather_kernel, dim3((nq + 127) / 128), dim3(128), 0, s, keep, n_out, xyxy, score, cls, out_boxes,
+                         out_scores, out_classes);
+      if (hipStreamSynchronize(s) != hipSuccess) r = OVM_ERR_HIP;
+    }
   }
   for (void* p : tmp) (void)hipFree(p);
   return r;

@@ -55,6 +55,9 @@ int det2d_alloc(Det2dWorkspace* w, int B, int G, int C, int num_classes, int max
 int det2d_forward(const Det2dModel& m, Det2dWorkspace& w, float* boxes, float* scores, int* classes, int* image_idx,
                   float* scores_full, int* out_counts, hipStream_t s);
 // Standalone class-agnostic NMS (torchvision.ops.nms semantics): keep_idx in decreasing-score order.
-int launch_nms_single(const float* boxes, const float* scores, int n, float thresh, int* keep_idx, int* n_keep, hipStream_t s);
+int launch_nms_single(const float* boxes, const float* scores, const int* valid, int n, float thresh, int* keep_idx, int* n_keep,
+                      hipStream_t s);
+int launch_gdino_post(const float* logits, int nq, int ld, const float* cxcywh, const int* spans, int K, int img_h, int img_w,
+                      float box_thr, float nms_thr, float* out_boxes, float* out_scores, int* out_classes, int* n_out, hipStream_t s);
 
 }  // namespace ovm

@@ -162,7 +162,14 @@ int ovm_tune_set(const char* key, int32_t value) {
 
 int ovm_op_nms(const float* boxes, const float* scores, int32_t n, float thresh, int32_t* keep_idx, int32_t* n_keep,
                ovm_stream_t stream) {
-  return launch_nms_single(boxes, scores, n, thresh, keep_idx, n_keep, (hipStream_t)stream);
+  return launch_nms_single(boxes, scores, nullptr, n, thresh, keep_idx, n_keep, (hipStream_t)stream);
+}
+
+int ovm_gdino_postprocess(const float* pred_logits, int32_t nq, int32_t ld, const float* pred_boxes, const int32_t* spans, int32_t n_phrases,
+                          int32_t img_h, int32_t img_w, float box_threshold, float nms_threshold, float* out_boxes, float* out_scores,
+                          int32_t* out_classes, int32_t* n_out, ovm_stream_t stream) {
+  return launch_gdino_post(pred_logits, nq, ld, pred_boxes, spans, n_phrases, img_h, img_w, box_threshold, nms_threshold, out_boxes,
+                           out_scores, out_classes, n_out, (hipStream_t)stream);
 }
 
 }  // extern "C"

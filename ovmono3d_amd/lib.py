@@ -49,7 +49,7 @@ EXPORTS = [
     "ovm_rpn_box_forward", "ovm_gather_records", "ovm_host_interp_pos_embed", "ovm_host_shard_range",
     "ovm_op_split_f16", "ovm_op_gemm", "ovm_op_layernorm", "ovm_op_attention", "ovm_op_roi_align",
     "ovm_op_cube_decode", "ovm_op_nms", "ovm_debug_copy", "ovm_profile_enable", "ovm_profile_read",
-    "ovm_comm_unique_id", "ovm_comm_init", "ovm_comm_destroy", "ovm_tune_set",
+    "ovm_comm_unique_id", "ovm_comm_init", "ovm_comm_destroy", "ovm_tune_set", "ovm_gdino_postprocess",
 ]
 PROF_NAMES = ("attn", "qkv", "proj", "fc1", "fc2", "ln")
 
@@ -93,6 +93,7 @@ def load() -> C.CDLL:
     lib.ovm_comm_init.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     lib.ovm_comm_destroy.argtypes = [vp]
     lib.ovm_tune_set.argtypes = [C.c_char_p, i32]
+    lib.ovm_gdino_postprocess.argtypes = [vp, i32, i32, vp, C.POINTER(i32), i32, i32, i32, f32, f32, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         if name not in ("ovm_last_error", "ovm_version", "ovm_debug_copy"):
             getattr(lib, name).restype = i32

@@ -4,13 +4,13 @@
 ``_forward_cube``; as in the reference the RPN/box-head result is not used for the boxes (:118-171)
 and batch size is 1 (:130-134, rcnn3d.py:108-109).
 
-The detector is pluggable: ``self.detector(image_u8_chw, category_list) -> dict(bboxes [n,4] xyxy at
-network resolution, scores [n], labels list[str])``. The reference-owned glue around GroundingDINO
-(caption building :176-181, phrase-logit reduction :273-294, threshold :197, cxcywh->xyxy :266-270,
-NMS :254, class index :162) is in ``ovmono3d_amd.modeling.roi_heads.gdino_glue``; the GroundingDINO
-network itself (Swin-B + BERT + deformable transformer, third-party, not in the reference tree) is the
-next row of the scope table and is NOT implemented in this round - without a detector ``forward``
-raises instead of silently falling back.
+The network is pluggable: ``self.detector(image_u8_chw, caption) -> dict`` returning EITHER the raw
+GroundingDINO outputs ``{"pred_logits": [nq,256], "pred_boxes": [nq,4] cxcywh, "input_ids": caption token ids,
+"phrase_ids": per-category token ids}`` - the reference-owned glue (caption building :176-181, phrase-logit
+reduction :273-294, threshold :197, cxcywh->xyxy :266-270, NMS :254, class index :162) then runs natively
+(``gdino_glue`` + ``ovm_gdino_postprocess``) - OR already post-processed ``{"bboxes", "scores", "labels"}``.
+The GroundingDINO network itself (Swin-B + BERT + deformable transformer, third-party, not in the reference
+tree) is NOT implemented in this round: without a detector ``forward`` raises instead of silently falling back.
 """
 from __future__ import annotations
 
@@ -45,12 +45,23 @@ class ROIHeads3DGDINO(ROIHeads3D):
                 "no text-prompted 2D detector attached: the native GroundingDINO network is not part of this "
                 "round (DESIGN.md, scope row a10). Attach one with roi_heads.detector = callable, or feed "
                 "oracle2D boxes / use MODEL.ROI_HEADS.NAME ROIHeads3D.")
-        det = self.detector(images.raw[0], [t[0] for t in filtered_texts])
+        from .gdino_glue import build_caption, gdino_postprocess, phrase_spans
+        caption, cap_list = build_caption([t[0] for t in filtered_texts])
+        det = self.detector(images.raw[0], caption)
         target = Instances(im_dims[0])
-        class_names = det["labels"]
+        if "pred_logits" in det:
+            spans = phrase_spans(det["input_ids"], det["phrase_ids"])
+            dev = self.engine.device
+            boxes, scores, cls = gdino_postprocess(det["pred_logits"].to(dev), det["pred_boxes"].to(dev), spans, im_dims[0],
+                                                   box_threshold=0.001, nms_threshold=0.5)          # :148, :254
+            class_names = [cap_list[int(i)] for i in cls.cpu()]
+        else:
+            boxes = torch.as_tensor(det["bboxes"], dtype=torch.float32).reshape(-1, 4)
+            scores = torch.as_tensor(det["scores"], dtype=torch.float32)
+            class_names = det["labels"]
         target.pred_classes = torch.tensor([filtered_texts.index([c]) for c in class_names], dtype=torch.int64)  # :162
-        target.pred_boxes = Boxes(torch.as_tensor(det["bboxes"], dtype=torch.float32).reshape(-1, 4))
-        target.scores = torch.as_tensor(det["scores"], dtype=torch.float32)
+        target.pred_boxes = Boxes(boxes)
+        target.scores = scores
         pred = [target]
         if self.loss_w_3d > 0:
             pred = self._forward_cube(features, pred, Ks, im_dims, im_scales_ratio, images=images, postprocess=fuse)

@@ -232,3 +232,29 @@ def test_nms_op(device, n):
     assert rc == 0
     k = int(nk.item())
     assert keep[:k].cpu().tolist() == ref.tolist()
+
+
+def test_gdino_glue_matches_oracle(device):
+    """ROIHeads3DGDINO's output glue (reference roi_heads_gdino.py:186-202,253-254,273-294) on synthetic network outputs."""
+    from oracle.gdino_glue import build_caption, gdino_postprocess as ref_post, phrase_spans
+    from ovmono3d_amd.modeling.roi_heads.gdino_glue import gdino_postprocess
+    cats = ["chair", "dining table", "potted plant"]
+    caption, cap_list = build_caption(cats)
+    assert caption == "chair . dining table . potted plant ."
+    # fake WordPiece ids: [CLS] chair . dining table . potted plant . [SEP]
+    phrase_ids = [[11], [21, 22], [31, 32, 33]]
+    ids = [101, 11, 1012, 21, 22, 1012, 31, 32, 33, 1012, 102]
+    spans = phrase_spans(ids, phrase_ids)
+    assert spans == [(1, 2), (3, 5), (6, 9)]
+    g = torch.Generator().manual_seed(0)
+    nq = 900
+    logits = torch.randn(nq, 256, generator=g) * 2 - 6          # most queries far below the 0.001 threshold
+    logits[::7, 1:9] += 6
+    logits[:, len(ids):] = float("-inf")                         # padded text positions (sigmoid -> 0)
+    boxes = torch.rand(nq, 4, generator=g) * torch.tensor([1.0, 1.0, 0.4, 0.4])
+    rb, rs, rc = ref_post(logits, boxes, spans, cap_list, [[c] for c in cats], (532, 709))
+    b, s, c = gdino_postprocess(logits.to(device), boxes.to(device), spans, (532, 709))
+    assert len(rs) > 20 and len(rs) == len(s)
+    assert torch.equal(c.cpu(), rc)
+    assert_close(b, rb, 1e-5, "gdino boxes")
+    assert_close(s, rs, 1e-5, "gdino scores")

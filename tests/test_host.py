@@ -111,3 +111,20 @@ def test_gdino_head_requires_category_list_and_detector():
         h.forward(il, {}, None, [], [1.0], None, category_list=None)
     with pytest.raises(NotImplementedError):
         h.forward(il, {}, None, [], [1.0], None, category_list=["chair"])
+
+
+def test_wordpiece_tokenizer_and_caption(tmp_path):
+    from ovmono3d_amd.modeling.roi_heads.gdino_glue import WordPieceTokenizer, build_caption, phrase_spans
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", ".", "chair", "din", "##ing", "table", "cereal", "box", "shoe", "##s"]
+    vf = tmp_path / "vocab.txt"
+    vf.write_text("\n".join(vocab) + "\n")
+    tok = WordPieceTokenizer(str(vf))
+    caption, caps = build_caption(["Chair", "dining table", "cereal box", "shoes"])
+    assert caption == "chair . dining table . cereal box . shoes ."           # reference roi_heads_gdino.py:176-181
+    assert tok.tokenize(caption) == ["chair", ".", "din", "##ing", "table", ".", "cereal", "box", ".", "shoe", "##s", "."]
+    ids = tok.encode(caption)
+    phrases = [tok.encode(c.lower(), add_special_tokens=False) for c in caps]
+    assert phrase_spans(ids, phrases) == [(1, 2), (3, 6), (7, 9), (10, 12)]
+    assert tok.tokenize("zebra") == ["[UNK]"]
+    with pytest.raises(AssertionError):
+        phrase_spans(ids, [[5], [99]])
