@@ -191,6 +191,30 @@ int ovm_gdino_postprocess(const float* pred_logits, int32_t nq, int32_t ld, cons
                           int32_t n_phrases, int32_t img_h, int32_t img_w, float box_threshold, float nms_threshold,
                           float* out_boxes, float* out_scores, int32_t* out_classes, int32_t* n_out, ovm_stream_t stream);
 
+/* --- generic device ops the GroundingDINO branch (ROIHeads3DGDINO's network, reference roi_heads_gdino.py:186) is
+ * sequenced from: fp32 row-major tensors in HBM, one call per op, all arithmetic on the device. */
+int ovm_g_pack_weight(const float* w, int32_t N, int32_t K, int32_t Kpad, uint16_t* hi, uint16_t* lo, ovm_stream_t stream);
+int ovm_g_linear(const float* x, int32_t ldx, int32_t M, int32_t K, const uint16_t* w_hi, const uint16_t* w_lo, int32_t N, int32_t Kpad,
+                 const float* bias, int32_t act /* 0 none, 1 relu, 2 gelu */, const float* residual, int32_t ldr, float* y, int32_t ldy,
+                 int32_t precision, ovm_stream_t stream);
+int ovm_g_layernorm(const float* x, const float* residual, int32_t M, int32_t D, const float* gamma, const float* beta, float eps, float* y,
+                    ovm_stream_t stream);
+int ovm_g_bmm(const float* a, const float* b, float* c, int32_t batch, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc,
+              int64_t sA, int64_t sB, int64_t sC, int32_t transB, float alpha, ovm_stream_t stream);
+int ovm_g_softmax(float* x, int32_t rows, int32_t cols, int32_t ld, const float* bias, int32_t bias_rows, int32_t bias_div, int32_t bias_ld,
+                  ovm_stream_t stream);
+int ovm_g_eltwise(int32_t op, const float* a, const float* b, float* out, int64_t n, int64_t bmod, float alpha, float beta, ovm_stream_t stream);
+int ovm_g_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, int64_t n_out, int32_t nidx, int32_t cols, float* dst,
+                      ovm_stream_t stream);
+int ovm_g_groupnorm(const float* x, int32_t B, int32_t HW, int32_t C, int32_t groups, const float* gamma, const float* beta, float eps, float* y,
+                    ovm_stream_t stream);
+int ovm_g_msdeform(const float* value, const int32_t* shapes_hw, int32_t L, int32_t B, int32_t S, int32_t Q, int32_t H, int32_t dh, int32_t P,
+                   const float* loc, const float* w, float* out, ovm_stream_t stream);
+int ovm_g_sine_embed(const float* pos, int64_t n, int32_t nc, int32_t F, float temperature, float* out, ovm_stream_t stream);
+int ovm_g_normalize_image(const OvmImage* image, const float* mean, const float* stdv, int32_t flip_channels, float* out_nhwc,
+                          ovm_stream_t stream);
+int ovm_g_topk(const float* scores, int32_t n, int32_t k, int32_t* out_idx, ovm_stream_t stream);
+
 /* tuning knob for experiments: key "gemm_bm" = 0 (heuristic) | 128 | 256 */
 int ovm_tune_set(const char* key, int32_t value);
 

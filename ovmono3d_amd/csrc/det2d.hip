@@ -644,4 +644,23 @@ int launch_gdino_post(const float* logits, int nq, int ld, const float* cxcywh, 
   return r;
 }
 
+// top-k indices by decreasing score (ties: lower index first), n <= 2^24
+namespace {
+__global__ void topk_emit_kernel(const unsigned long long* __restrict__ keys, int k, int* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < k) out[i] = (int)(keys[i] & kIdMask);
+}
+}  // namespace
+int launch_topk(const float* scores, int n, int k, int* out_idx, hipStream_t s) {
+  if (k > n || n <= 0) return OVM_ERR_INVALID;
+  const int N = pow2_at_least(n);
+  static unsigned long long* keys = nullptr; static int cap = 0;
+  if (cap < N) { if (keys) { (void)hipDeviceSynchronize(); (void)hipFree(keys); } if (hipMalloc((void**)&keys, sizeof(unsigned long long) * N) != hipSuccess) { keys = nullptr; cap = 0; return OVM_ERR_HIP; } cap = N; }
+  hipLaunchKernelGGL(single_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, s, scores, (const int*)nullptr, n, N, keys);
+  int r = sort_keys(keys, N, 1, s);
+  if (r) return r;
+  hipLaunchKernelGGL(topk_emit_kernel, dim3((k + 255) / 256), dim3(256), 0, s, keys, k, out_idx);
+  return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
+
 }  // namespace ovm

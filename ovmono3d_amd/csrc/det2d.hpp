@@ -57,6 +57,7 @@ int det2d_forward(const Det2dModel& m, Det2dWorkspace& w, float* boxes, float* s
 // Standalone class-agnostic NMS (torchvision.ops.nms semantics): keep_idx in decreasing-score order.
 int launch_nms_single(const float* boxes, const float* scores, const int* valid, int n, float thresh, int* keep_idx, int* n_keep,
                       hipStream_t s);
+int launch_topk(const float* scores, int n, int k, int* out_idx, hipStream_t s);
 int launch_gdino_post(const float* logits, int nq, int ld, const float* cxcywh, const int* spans, int K, int img_h, int img_w,
                       float box_thr, float nms_thr, float* out_boxes, float* out_scores, int* out_classes, int* n_out, hipStream_t s);
 

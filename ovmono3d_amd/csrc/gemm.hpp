@@ -33,7 +33,8 @@ struct GemmParams {
   float* X; int ldx;                              // EPI_RESID: fp32 residual stream, in place
   float* C; int ldc;                              // EPI_STORE: fp32 out (or null)
   half_t* Ohi; half_t* Olo; int ldo;              // EPI_STORE / EPI_GELU / EPI_CONVT: fp16 split out (or null)
-  int relu;
+  int relu;                                       // EPI_STORE activation: 0 none, 1 ReLU, 2 GELU(erf)
+  const float* R; int ldr;                        // EPI_STORE: optional fp32 residual added after the activation
   // EPI_STORE with padded-NHWC destination for Ohi/Olo (conv input): if padH>0, row m=(b,y,x) goes to
   // ((b*(padH+2) + y+1)*(padW+2) + x+1)
   int padH, padW;
@@ -149,7 +150,11 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32
   } else {  // EPI_STORE
     float o4[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { o4[r] = v[r] + b4[r]; if (p.relu) o4[r] = fmaxf(o4[r], 0.f); }
+    for (int r = 0; r < 4; ++r) {
+      o4[r] = v[r] + b4[r];
+      if (p.relu == 1) o4[r] = fmaxf(o4[r], 0.f); else if (p.relu == 2) o4[r] = gelu_erf(o4[r]);
+      if (p.R && n + r < p.N) o4[r] += p.R[(size_t)m * p.ldr + n + r];
+    }
     if (p.C) {
       float* c = p.C + (size_t)m * p.ldc + n;
       for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = o4[r];
