@@ -201,6 +201,11 @@ int ovm_g_layernorm(const float* x, const float* residual, int32_t M, int32_t D,
                     ovm_stream_t stream);
 int ovm_g_bmm(const float* a, const float* b, float* c, int32_t batch, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc,
               int64_t sA, int64_t sB, int64_t sC, int32_t transB, float alpha, ovm_stream_t stream);
+int ovm_g_bmm2(const float* a, const float* b, float* c, int32_t nb1, int32_t nb2, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
+               int32_t ldc, int64_t sA1, int64_t sB1, int64_t sC1, int64_t sA2, int64_t sB2, int64_t sC2, int32_t transB, float alpha,
+               ovm_stream_t stream);
+int ovm_g_softmax2(float* x, int32_t rows, int32_t cols, int32_t ld, const float* bias, int32_t bias_rows, int32_t bias_div, int32_t bias_ld,
+                   const float* bias2, int32_t d2, int32_t m2, ovm_stream_t stream);
 int ovm_g_softmax(float* x, int32_t rows, int32_t cols, int32_t ld, const float* bias, int32_t bias_rows, int32_t bias_div, int32_t bias_ld,
                   ovm_stream_t stream);
 int ovm_g_eltwise(int32_t op, const float* a, const float* b, float* out, int64_t n, int64_t bmod, float alpha, float beta, ovm_stream_t stream);

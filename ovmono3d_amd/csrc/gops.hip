@@ -64,12 +64,14 @@ __global__ __launch_bounds__(256) void ln_generic_kernel(const float* __restrict
 }
 
 // c[b] = alpha * a[b] (M x K) * op(b[b]) ; op = transpose when transB (b is N x K), else b is K x N. fp32 FMA, 16x16 tiles.
+// batch index z = z1 * nb2 + z2 with independent strides per level (e.g. window x head)
 __global__ __launch_bounds__(256) void bmm_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ Cm,
                                                   int M, int N, int K, int lda, int ldb, int ldc, long sA, long sB, long sC,
-                                                  int transB, float alpha) {
+                                                  int nb2, long sA2, long sB2, long sC2, int transB, float alpha) {
   __shared__ float As[16][17], Bs[16][17];
-  const int bz = blockIdx.z;
-  const float* a = A + (size_t)bz * sA; const float* b = Bm + (size_t)bz * sB; float* c = Cm + (size_t)bz * sC;
+  const int z1 = blockIdx.z / nb2, z2 = blockIdx.z - z1 * nb2;
+  const float* a = A + (size_t)z1 * sA + (size_t)z2 * sA2; const float* b = Bm + (size_t)z1 * sB + (size_t)z2 * sB2;
+  float* c = Cm + (size_t)z1 * sC + (size_t)z2 * sC2;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
   float acc = 0.f;
@@ -87,17 +89,21 @@ __global__ __launch_bounds__(256) void bmm_kernel(const float* __restrict__ A, c
 }
 
 // x[r][:] = softmax(x[r][:] + bias[(r / bias_div) % bias_rows][:]) ; one wave per row
+// optional second additive term bias2[(row / d2) * m2 + row % m2][:]  (e.g. the per-window shift mask next to the per-head
+// relative-position bias of Swin attention)
 __global__ __launch_bounds__(256) void softmax_kernel(float* __restrict__ x, int rows, int cols, int ld, const float* __restrict__ bias,
-                                                      int bias_rows, int bias_div, int bias_ld) {
+                                                      int bias_rows, int bias_div, int bias_ld, const float* __restrict__ bias2, int d2,
+                                                      int m2) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   float* xr = x + (size_t)row * ld;
   const float* br = bias ? bias + (size_t)((row / bias_div) % bias_rows) * bias_ld : nullptr;
+  const float* b2 = bias2 ? bias2 + ((size_t)(row / d2) * m2 + (row % m2)) * bias_ld : nullptr;
   float mx = -INFINITY;
-  for (int j = lane; j < cols; j += 64) mx = fmaxf(mx, xr[j] + (br ? br[j] : 0.f));
+  for (int j = lane; j < cols; j += 64) mx = fmaxf(mx, xr[j] + (br ? br[j] : 0.f) + (b2 ? b2[j] : 0.f));
   mx = wave_max(mx);
   float s = 0.f;
-  for (int j = lane; j < cols; j += 64) { const float e = expf(xr[j] + (br ? br[j] : 0.f) - mx); xr[j] = e; s += e; }
+  for (int j = lane; j < cols; j += 64) { const float e = expf(xr[j] + (br ? br[j] : 0.f) + (b2 ? b2[j] : 0.f) - mx); xr[j] = e; s += e; }
   s = wave_sum(s);
   const float inv = 1.0f / s;
   for (int j = lane; j < cols; j += 64) xr[j] *= inv;
@@ -258,17 +264,34 @@ int ovm_g_layernorm(const float* x, const float* residual, int32_t M, int32_t D,
 
 int ovm_g_bmm(const float* a, const float* b, float* c, int32_t batch, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb, int32_t ldc,
               int64_t sA, int64_t sB, int64_t sC, int32_t transB, float alpha, ovm_stream_t stream) {
-  if (batch <= 0 || M <= 0 || N <= 0) return OVM_OK;
-  hipLaunchKernelGGL(bmm_kernel, dim3((N + 15) / 16, (M + 15) / 16, batch), dim3(256), 0, (hipStream_t)stream, a, b, c, M, N, K, lda, ldb, ldc,
-                     (long)sA, (long)sB, (long)sC, transB, alpha);
+  return ovm_g_bmm2(a, b, c, batch, 1, M, N, K, lda, ldb, ldc, sA, sB, sC, 0, 0, 0, transB, alpha, stream);
+}
+
+int ovm_g_bmm2(const float* a, const float* b, float* c, int32_t nb1, int32_t nb2, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldb,
+               int32_t ldc, int64_t sA1, int64_t sB1, int64_t sC1, int64_t sA2, int64_t sB2, int64_t sC2, int32_t transB, float alpha,
+               ovm_stream_t stream) {
+  if (nb1 <= 0 || nb2 <= 0 || M <= 0 || N <= 0) return OVM_OK;
+  const long nz = (long)nb1 * nb2;
+  for (long z0 = 0; z0 < nz; z0 += 65535 / nb2 * nb2) {          // grid.z limit; chunks keep z2 aligned
+    const long cnt = (nz - z0 < (long)(65535 / nb2 * nb2)) ? nz - z0 : (long)(65535 / nb2 * nb2);
+    const long o1 = z0 / nb2;
+    hipLaunchKernelGGL(bmm_kernel, dim3((N + 15) / 16, (M + 15) / 16, (unsigned)cnt), dim3(256), 0, (hipStream_t)stream, a + o1 * sA1,
+                       b + o1 * sB1, c + o1 * sC1, M, N, K, lda, ldb, ldc, (long)sA1, (long)sB1, (long)sC1, nb2, (long)sA2, (long)sB2,
+                       (long)sC2, transB, alpha);
+  }
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 
 int ovm_g_softmax(float* x, int32_t rows, int32_t cols, int32_t ld, const float* bias, int32_t bias_rows, int32_t bias_div, int32_t bias_ld,
                   ovm_stream_t stream) {
+  return ovm_g_softmax2(x, rows, cols, ld, bias, bias_rows, bias_div, bias_ld, nullptr, 1, 1, stream);
+}
+
+int ovm_g_softmax2(float* x, int32_t rows, int32_t cols, int32_t ld, const float* bias, int32_t bias_rows, int32_t bias_div, int32_t bias_ld,
+                   const float* bias2, int32_t d2, int32_t m2, ovm_stream_t stream) {
   if (rows <= 0) return OVM_OK;
   hipLaunchKernelGGL(softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, bias, bias_rows > 0 ? bias_rows : 1,
-                     bias_div > 0 ? bias_div : 1, bias_ld);
+                     bias_div > 0 ? bias_div : 1, bias_ld, bias2, d2 > 0 ? d2 : 1, m2 > 0 ? m2 : 1);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 

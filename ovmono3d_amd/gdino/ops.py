@@ -81,6 +81,12 @@ class Ops:
         self._chk(self.L.ovm_g_bmm(a.data_ptr() + a_off * es, b.data_ptr() + b_off * es, c.data_ptr() + c_off * es, batch, M, N, K,
                                    lda, ldb, ldc, sA, sB, sC, int(transB), float(alpha), self._s()), "ovm_g_bmm")
 
+    def bmm2_raw(self, a, a_off, b, b_off, c, c_off, nb1, nb2, M, N, K, lda, ldb, ldc, sA1, sB1, sC1, sA2, sB2, sC2, transB, alpha=1.0):
+        """two-level batch (z = z1*nb2 + z2), e.g. (window, head)."""
+        es = 4
+        self._chk(self.L.ovm_g_bmm2(a.data_ptr() + a_off * es, b.data_ptr() + b_off * es, c.data_ptr() + c_off * es, nb1, nb2, M, N, K,
+                                    lda, ldb, ldc, sA1, sB1, sC1, sA2, sB2, sC2, int(transB), float(alpha), self._s()), "ovm_g_bmm2")
+
     def bmm(self, a: torch.Tensor, b: torch.Tensor, transB: bool, alpha: float = 1.0) -> torch.Tensor:
         """a [Bt,M,K]; b [Bt,N,K] if transB else [Bt,K,N]; contiguous."""
         a, b = a.contiguous(), b.contiguous()
@@ -95,6 +101,14 @@ class Ops:
         assert x.is_contiguous()
         self._chk(self.L.ovm_g_softmax(x.data_ptr(), rows, cols, cols, bias.data_ptr() if bias is not None else None, bias_rows, bias_div,
                                        bias.shape[-1] if bias is not None else 0, self._s()), "ovm_g_softmax")
+        return x
+
+    def softmax2_(self, x: torch.Tensor, bias, bias_rows, bias_div, bias2, d2, m2):
+        """x[r] = softmax(x[r] + bias[(r//bias_div) % bias_rows] + bias2[(r//d2)*m2 + r % m2])"""
+        rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+        assert x.is_contiguous()
+        self._chk(self.L.ovm_g_softmax2(x.data_ptr(), rows, cols, cols, bias.data_ptr() if bias is not None else None, bias_rows, bias_div,
+                                        cols, bias2.data_ptr() if bias2 is not None else None, d2, m2, self._s()), "ovm_g_softmax2")
         return x
 
     # ---- element-wise / gathers ---------------------------------------------------------------

@@ -97,3 +97,29 @@ def test_bert_text_encoder_matches_hf(device):
     enc = BertEncoder(_ops(device), sd)
     out = enc.forward(ids, mask, pos)
     assert_close(out, ref, 2e-5, "bert last hidden state")
+
+
+def test_swin_backbone_matches_hf(device):
+    from transformers import SwinBackbone as HFSwin, SwinConfig
+    from ovmono3d_amd.gdino.swin import SwinBackbone
+    torch.manual_seed(0)
+    cfg = SwinConfig(image_size=384, patch_size=4, embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=12,
+                     out_indices=[2, 3, 4], layer_norm_eps=1e-5)
+    hf = HFSwin(cfg).eval()
+    with torch.no_grad():
+        for n_, p_ in hf.named_parameters():
+            if "relative_position_bias_table" in n_:
+                p_.normal_(0, 0.5)
+            elif p_.dim() > 1:
+                p_.mul_(2.5)
+    H, W = 100, 130                                             # not multiples of the patch / window sizes: exercises all padding
+    img = torch.randn(1, 3, H, W)
+    with torch.no_grad():
+        ref = hf(img).feature_maps
+    sd = {"bb." + k: v for k, v in hf.state_dict().items()}
+    net = SwinBackbone(_ops(device), sd, "bb.", 32, cfg.depths, cfg.num_heads, window=12)
+    outs = net.forward(img[0].permute(1, 2, 0).reshape(H * W, 3).contiguous().to(device), H, W)
+    assert len(outs) == 3
+    for (f, h, w), r in zip(outs, ref):
+        assert (h, w) == tuple(r.shape[-2:])
+        assert_close(f.view(h, w, -1).permute(2, 0, 1), r[0], 3e-5, f"swin stage {h}x{w}")
