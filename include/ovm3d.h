@@ -218,6 +218,7 @@ int ovm_g_msdeform(const float* value, const int32_t* shapes_hw, int32_t L, int3
 int ovm_g_sine_embed(const float* pos, int64_t n, int32_t nc, int32_t F, float temperature, float* out, ovm_stream_t stream);
 int ovm_g_normalize_image(const OvmImage* image, const float* mean, const float* stdv, int32_t flip_channels, float* out_nhwc,
                           ovm_stream_t stream);
+int ovm_g_rowmax(const float* x, int32_t rows, int32_t cols, int32_t ld, float* out, ovm_stream_t stream);
 int ovm_g_topk(const float* scores, int32_t n, int32_t k, int32_t* out_idx, ovm_stream_t stream);
 
 /* tuning knob for experiments: key "gemm_bm" = 0 (heuristic) | 128 | 256 */

@@ -126,11 +126,21 @@ __global__ void eltwise_kernel(int op, const float* __restrict__ a, const float*
     case E_SIGMOID: r = 1.0f / (1.0f + expf(-x)); break;
     case E_CLAMP: r = fminf(fmaxf(x, alpha), beta); break;
     case E_AXPY: r = x + alpha * y; break;
-    case E_INVSIG: { const float xc = fminf(fmaxf(x, 0.f), 1.f); r = logf(fmaxf(xc, alpha) / fmaxf(1.f - xc, alpha)); break; }
+    case E_INVSIG: { const float xc = fminf(fmaxf(x, alpha), 1.f - alpha); r = logf(xc / (1.f - xc)); break; }   // torch.special.logit(x, eps)
     case E_MASKFILL: r = (y != 0.f) ? alpha : x; break;
     default: r = x;
   }
   out[i] = r;
+}
+
+// out[r] = max_j x[r][j] ; one wave per row
+__global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ x, int rows, int cols, int ld, float* __restrict__ out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float m = -INFINITY;
+  for (int j = lane; j < cols; j += 64) m = fmaxf(m, x[(size_t)row * ld + j]);
+  m = wave_max(m);
+  if (lane == 0) out[row] = m;
 }
 
 // dst[i][j*cols .. (j+1)*cols) = idx[i*nidx+j] >= 0 ? src[idx][0..cols) : 0
@@ -332,6 +342,12 @@ int ovm_g_normalize_image(const OvmImage* image, const float* mean, const float*
   ImageDesc d{image->data, image->height, image->width, image->stride_c, image->stride_h, image->stride_w};
   hipLaunchKernelGGL(normalize_image_kernel, g1((long)d.H * d.W * 3), dim3(256), 0, (hipStream_t)stream, d, mean[0], mean[1], mean[2], stdv[0],
                      stdv[1], stdv[2], flip_channels, out_nhwc);
+  return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
+
+int ovm_g_rowmax(const float* x, int32_t rows, int32_t cols, int32_t ld, float* out, ovm_stream_t stream) {
+  if (rows <= 0) return OVM_OK;
+  hipLaunchKernelGGL(rowmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, out);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 

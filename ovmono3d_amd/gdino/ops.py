@@ -164,6 +164,21 @@ class Ops:
         self._chk(self.L.ovm_g_sine_embed(pos.data_ptr(), n, nc, F, float(temperature), out.data_ptr(), self._s()), "ovm_g_sine_embed")
         return out
 
+    def rowmax(self, x: torch.Tensor) -> torch.Tensor:
+        assert x.dim() == 2 and x.stride(1) == 1
+        out = self.empty(x.shape[0])
+        self._chk(self.L.ovm_g_rowmax(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), out.data_ptr(), self._s()), "ovm_g_rowmax")
+        return out
+
+    def normalize_image(self, image_desc, mean, std, flip: bool) -> torch.Tensor:
+        """image_desc: lib.OvmImage (uint8, device). Returns fp32 [H*W, 3] NHWC, optionally channel-flipped."""
+        H, W = int(image_desc.height), int(image_desc.width)
+        out = self.empty(H * W, 3)
+        m = (C.c_float * 3)(*[float(v) for v in mean])
+        s = (C.c_float * 3)(*[float(v) for v in std])
+        self._chk(self.L.ovm_g_normalize_image(C.byref(image_desc), m, s, int(flip), out.data_ptr(), self._s()), "ovm_g_normalize_image")
+        return out
+
     def topk(self, scores: torch.Tensor, k: int) -> torch.Tensor:
         scores = scores.contiguous()
         out = torch.empty(k, dtype=torch.int32, device=self.dev)

@@ -51,7 +51,7 @@ EXPORTS = [
     "ovm_op_cube_decode", "ovm_op_nms", "ovm_debug_copy", "ovm_profile_enable", "ovm_profile_read",
     "ovm_comm_unique_id", "ovm_comm_init", "ovm_comm_destroy", "ovm_tune_set", "ovm_gdino_postprocess",
     "ovm_g_pack_weight", "ovm_g_linear", "ovm_g_layernorm", "ovm_g_bmm", "ovm_g_bmm2", "ovm_g_softmax", "ovm_g_softmax2", "ovm_g_eltwise", "ovm_g_gather_rows",
-    "ovm_g_groupnorm", "ovm_g_msdeform", "ovm_g_sine_embed", "ovm_g_normalize_image", "ovm_g_topk",
+    "ovm_g_groupnorm", "ovm_g_msdeform", "ovm_g_sine_embed", "ovm_g_normalize_image", "ovm_g_topk", "ovm_g_rowmax",
 ]
 PROF_NAMES = ("attn", "qkv", "proj", "fc1", "fc2", "ln")
 
@@ -109,6 +109,7 @@ def load() -> C.CDLL:
     lib.ovm_g_sine_embed.argtypes = [vp, i64, i32, i32, f32, vp, vp]
     lib.ovm_g_normalize_image.argtypes = [C.POINTER(OvmImage), C.POINTER(f32), C.POINTER(f32), i32, vp, vp]
     lib.ovm_g_topk.argtypes = [vp, i32, i32, vp, vp]
+    lib.ovm_g_rowmax.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.ovm_gdino_postprocess.argtypes = [vp, i32, i32, vp, C.POINTER(i32), i32, i32, i32, f32, f32, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         if name not in ("ovm_last_error", "ovm_version", "ovm_debug_copy"):

@@ -123,3 +123,75 @@ def test_swin_backbone_matches_hf(device):
     for (f, h, w), r in zip(outs, ref):
         assert (h, w) == tuple(r.shape[-2:])
         assert_close(f.view(h, w, -1).permute(2, 0, 1), r[0], 3e-5, f"swin stage {h}x{w}")
+
+
+def _small_hf_gdino():
+    from transformers import BertConfig, GroundingDinoConfig, GroundingDinoForObjectDetection, SwinConfig
+    torch.manual_seed(0)
+    bb = SwinConfig(image_size=384, patch_size=4, embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=12,
+                    out_indices=[2, 3, 4], layer_norm_eps=1e-5)
+    tc = BertConfig(vocab_size=2000, hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
+                    max_position_embeddings=512, attn_implementation="eager")
+    cfg = GroundingDinoConfig(backbone_config=bb, text_config=tc, d_model=64, encoder_layers=2, decoder_layers=2,
+                              encoder_attention_heads=4, decoder_attention_heads=4, encoder_ffn_dim=128, decoder_ffn_dim=128,
+                              num_queries=30, num_feature_levels=4, encoder_n_points=4, decoder_n_points=4, max_text_len=256,
+                              positional_embedding_temperature=20, two_stage=True, embedding_init_target=True,
+                              decoder_bbox_embed_share=True, two_stage_bbox_embed_share=False, disable_custom_kernels=True,
+                              attn_implementation="eager")
+    hf = GroundingDinoForObjectDetection(cfg).eval()
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n_, p_ in hf.named_parameters():                    # HF's init is nearly inert (1e-4 gates, zeroed heads): perturb
+            if p_.dim() > 1:
+                p_.add_(torch.randn(p_.shape, generator=g) * 0.05)
+            elif "vision_param" in n_ or "text_param" in n_:
+                p_.copy_(0.5 + torch.rand(p_.shape, generator=g))
+            else:
+                p_.add_(torch.randn(p_.shape, generator=g) * 0.02)
+    # transformers 5.x's BertModel adds a 4-D bool mask as +1.0 (no masking); upstream GroundingDINO builds the additive
+    # mask (get_extended_attention_mask). Feed HF what upstream computes.
+    tb = hf.model.text_backbone
+    orig = tb.forward
+
+    def patched(input_ids, attention_mask=None, token_type_ids=None, position_ids=None, **kw):
+        if attention_mask is not None and attention_mask.dtype == torch.bool:
+            attention_mask = torch.where(attention_mask, 0.0, torch.finfo(torch.float32).min)
+        return orig(input_ids, attention_mask, token_type_ids, position_ids, **kw)
+    tb.forward = patched
+    # transformers 5.x's encode_sinusoidal_position_embedding casts its result back to the input dtype; the encoder layers call it
+    # with int64 text position ids, which truncates the text position embedding to integers. Upstream (get_sine_pos_embed) keeps
+    # floats; make HF do the same.
+    import transformers.models.grounding_dino.modeling_grounding_dino as mgd
+    if not getattr(mgd, "_ovm_patched", False):
+        orig_enc = mgd.encode_sinusoidal_position_embedding
+        mgd.encode_sinusoidal_position_embedding = lambda pos, **kw: orig_enc(pos.float(), **kw)
+        mgd._ovm_patched = True
+    return hf, cfg
+
+
+def test_full_gdino_network_matches_hf(device):
+    from transformers.models.grounding_dino.modeling_grounding_dino import generate_masks_with_special_tokens_and_transfer_map
+    from ovmono3d_amd.gdino.model import GDinoConfig, GroundingDinoNative
+    hf, cfg = _small_hf_gdino()
+    H, W = 96, 132
+    g = torch.Generator().manual_seed(2)
+    img = torch.randn(1, 3, H, W, generator=g)
+    ids = torch.tensor([101, 500, 1012, 600, 601, 1012, 700, 701, 702, 1012, 102])
+    with torch.no_grad():
+        out = hf(pixel_values=img, input_ids=ids[None], return_dict=True)
+    ref_logits, ref_boxes = out.logits[0], out.pred_boxes[0]
+    _, p_hf = generate_masks_with_special_tokens_and_transfer_map(ids[None])
+    ncfg = GDinoConfig(d_model=64, enc_layers=2, dec_layers=2, heads=4, ffn_dim=128, num_queries=30, bert_heads=2, swin_embed=32,
+                       swin_depths=(2, 2, 2, 2), swin_heads=(1, 2, 4, 8), swin_window=12)
+    net = GroundingDinoNative(_ops(device), hf.state_dict(), ncfg)
+    x = img[0].permute(1, 2, 0).reshape(H * W, 3).contiguous().to(device)
+    logits, boxes, aux = net.forward(x, H, W, ids, position_ids=p_hf[0], return_aux=True)
+    T = len(ids)
+    assert torch.isinf(logits[:, T:]).all() and (logits[:, T:] < 0).all()
+    # same queries selected by the two-stage top-k (random weights keep the margins wide)
+    hf_topk = torch.topk(out.enc_outputs_class[0].max(-1)[0], 30)[1]
+    assert sorted(aux["topk"].cpu().tolist()) == sorted(hf_topk.tolist())
+    assert_close(aux["enc_vision"], out.encoder_last_hidden_state_vision[0], 1e-4, "encoder vision")
+    assert_close(aux["enc_text"], out.encoder_last_hidden_state_text[0], 1e-4, "encoder text")
+    assert_close(boxes, ref_boxes, 2e-4, "pred_boxes")
+    assert_close(logits[:, :T], ref_logits[:, :T], 2e-4, "pred_logits")
