@@ -258,5 +258,8 @@ def get_cfg_defaults(cfg: CfgNode) -> CfgNode:
     cfg.MODEL.ROI_HEADS.POOLER_MAX_LEVEL = 4
     # GEMM operand precision of the HIP path: "f16" (one MFMA pass, f32 accumulate) or
     # "f16x3" (hi/lo split, three passes, ~f32 accuracy).
-    cfg.MODEL.AMD = CfgNode(dict(GEMM_PRECISION="f16", MAX_BATCH=1, MAX_ROIS=1000))
+    cfg.MODEL.AMD = CfgNode(dict(GEMM_PRECISION="f16x3", MAX_BATCH=1, MAX_ROIS=1000,
+                                 # GroundingDINO branch of ROIHeads3DGDINO: checkpoint (the reference hard-codes this path,
+                                 # roi_heads_gdino.py:87-91; "synthetic://gdino?seed=N" = random init) and bert-base-uncased vocab.txt
+                                 GDINO_WEIGHTS="./checkpoints/groundingdino_swinb_cogcoor.pth", BERT_VOCAB=""))
     return cfg

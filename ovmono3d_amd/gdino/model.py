@@ -214,7 +214,8 @@ class GroundingDinoNative:
 
     # ---- forward ----------------------------------------------------------------------------------
     def forward(self, img_nhwc: torch.Tensor, H: int, W: int, input_ids: torch.Tensor, position_ids: Optional[torch.Tensor] = None,
-                return_aux: bool = False):
+                return_aux: bool = False, force_topk: Optional[torch.Tensor] = None):
+        # force_topk (tests only): use this two-stage selection instead of the network's own, to compare decoders across near-ties
         """img_nhwc: device fp32 [H*W, 3] (normalised image as the reference hands it over, roi_heads_gdino.py:146);
         input_ids: int64 [T] = tokenizer(caption). Returns pred_logits [Q, max_text_len] (pre-sigmoid; -inf beyond the
         caption) and pred_boxes [Q, 4] (cx, cy, w, h in [0, 1])."""
@@ -295,7 +296,9 @@ class GroundingDinoNative:
         oq = o.gather_rows(vis, tb["valid_idx"])                                                          # invalid proposals -> zero rows
         oq = o.layernorm(o.linear(oq, self.enc_output), self.enc_output_ln[0], self.enc_output_ln[1], c.eps)
         cls = o.bmm(oq.view(1, S, D), text.view(1, T, D), True)[0]                                        # [S, T]
-        topk = o.topk(o.rowmax(cls), c.num_queries)
+        if S < c.num_queries:                         # torch.topk in the upstream two-stage selection raises the same way
+            raise RuntimeError(f"selected index k out of range: {S} encoder tokens < {c.num_queries} queries (image too small)")
+        topk = o.topk(o.rowmax(cls), c.num_queries) if force_topk is None else force_topk.to(o.dev, torch.int32)
         coord = o.add(self._mlp(oq, self.enc_bbox), tb["prop_logit"])
         ref = o.elt(O.SIGMOID, o.gather_rows(coord, topk.view(-1, 1)))                                    # [Q, 4]
         hs = self.tgt                                                                                     # embedding_init_target
@@ -316,6 +319,9 @@ class GroundingDinoNative:
             ff = o.linear(o.linear(hs, ly["fc1"], act=ACT_RELU), ly["fc2"], residual=hs)
             hs = o.layernorm(ff, ly["ln4"][0], ly["ln4"][1], c.eps)
             last_ref = ref
+            if return_aux:
+                aux.setdefault("dec_hs", []).append(hs)
+                aux.setdefault("dec_ref", []).append(ref)
             ref = o.elt(O.SIGMOID, o.add(self._mlp(hs, self.bbox[i]), o.elt(O.INVSIG, ref, alpha=1e-5)))
         hn = o.layernorm(hs, self.dec_ln[0], self.dec_ln[1], c.eps)
         logits_t = o.bmm(hn.view(1, Q, D), text.view(1, T, D), True)[0]                                   # [Q, T]

@@ -9,8 +9,9 @@ GroundingDINO outputs ``{"pred_logits": [nq,256], "pred_boxes": [nq,4] cxcywh, "
 "phrase_ids": per-category token ids}`` - the reference-owned glue (caption building :176-181, phrase-logit
 reduction :273-294, threshold :197, cxcywh->xyxy :266-270, NMS :254, class index :162) then runs natively
 (``gdino_glue`` + ``ovm_gdino_postprocess``) - OR already post-processed ``{"bboxes", "scores", "labels"}``.
-The GroundingDINO network itself (Swin-B + BERT + deformable transformer, third-party, not in the reference
-tree) is NOT implemented in this round: without a detector ``forward`` raises instead of silently falling back.
+By default the detector is the native GroundingDINO network (``ovmono3d_amd.gdino``: Swin-B + BERT + deformable
+transformer on libovm3d ops), built on first use from ``MODEL.AMD.GDINO_WEIGHTS``; if neither a checkpoint nor a detector
+is available ``forward`` raises instead of silently falling back.
 """
 from __future__ import annotations
 
@@ -28,6 +29,31 @@ class ROIHeads3DGDINO(ROIHeads3D):
     def __init__(self, cfg, input_shape=None, priors=None, engine=None, detector: Optional[Callable] = None):
         super().__init__(cfg, input_shape, priors=priors, engine=engine)
         self.detector = detector
+        self._gdino_cfg = cfg
+
+    def load_detector(self):
+        """Builds the native GroundingDINO (reference: load_model(...) in __init__, roi_heads_gdino.py:87-91). Deferred to
+        first use so that a model without the checkpoint can still serve the oracle-2D / RPN paths."""
+        import os
+        from ...checkpoint import load_state_dict_file
+        from ...gdino.detector import HashTokenizer, NativeGroundingDino
+        from .gdino_glue import WordPieceTokenizer
+        cfg = self._gdino_cfg
+        path = cfg.MODEL.AMD.GDINO_WEIGHTS
+        if path.startswith("synthetic://"):
+            from ...util.synth_gdino import synth_gdino_state_dict
+            seed = int(path.split("seed=")[1]) if "seed=" in path else 0
+            sd, tok = synth_gdino_state_dict(seed), HashTokenizer()
+        else:
+            if not os.path.isfile(path):
+                raise NotImplementedError(
+                    f"GroundingDINO checkpoint {path!r} not found (MODEL.AMD.GDINO_WEIGHTS) and no detector attached: "
+                    "ROIHeads3DGDINO cannot produce 2D boxes. There is no fallback.")
+            if not cfg.MODEL.AMD.BERT_VOCAB:
+                raise NotImplementedError("MODEL.AMD.BERT_VOCAB (bert-base-uncased vocab.txt) is required to tokenise the caption")
+            sd, tok = load_state_dict_file(path), WordPieceTokenizer(cfg.MODEL.AMD.BERT_VOCAB)
+        prec = 3 if cfg.MODEL.AMD.GEMM_PRECISION == "f16x3" else 1
+        self.detector = NativeGroundingDino(self.engine.device, sd, tok, cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, precision=prec)
 
     def forward(self, images, features, proposals, Ks, im_scales_ratio, targets=None, category_list=None):
         assert not self.training, "training is out of scope of the native inference path"
@@ -41,10 +67,7 @@ class ROIHeads3DGDINO(ROIHeads3D):
         if len(im_dims) != 1:
             raise ValueError("GroundingDINO inference supports one image per batch (reference rcnn3d.py:108)")
         if self.detector is None:
-            raise NotImplementedError(
-                "no text-prompted 2D detector attached: the native GroundingDINO network is not part of this "
-                "round (DESIGN.md, scope row a10). Attach one with roi_heads.detector = callable, or feed "
-                "oracle2D boxes / use MODEL.ROI_HEADS.NAME ROIHeads3D.")
+            self.load_detector()
         from .gdino_glue import build_caption, gdino_postprocess, phrase_spans
         caption, cap_list = build_caption([t[0] for t in filtered_texts])
         det = self.detector(images.raw[0], caption)

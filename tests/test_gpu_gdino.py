@@ -148,6 +148,11 @@ def _small_hf_gdino():
                 p_.copy_(0.5 + torch.rand(p_.shape, generator=g))
             else:
                 p_.add_(torch.randn(p_.shape, generator=g) * 0.02)
+    _patch_hf_to_upstream(hf)
+    return hf, cfg
+
+
+def _patch_hf_to_upstream(hf):
     # transformers 5.x's BertModel adds a 4-D bool mask as +1.0 (no masking); upstream GroundingDINO builds the additive
     # mask (get_extended_attention_mask). Feed HF what upstream computes.
     tb = hf.model.text_backbone
@@ -166,7 +171,6 @@ def _small_hf_gdino():
         orig_enc = mgd.encode_sinusoidal_position_embedding
         mgd.encode_sinusoidal_position_embedding = lambda pos, **kw: orig_enc(pos.float(), **kw)
         mgd._ovm_patched = True
-    return hf, cfg
 
 
 def test_full_gdino_network_matches_hf(device):
@@ -195,3 +199,47 @@ def test_full_gdino_network_matches_hf(device):
     assert_close(aux["enc_text"], out.encoder_last_hidden_state_text[0], 1e-4, "encoder text")
     assert_close(boxes, ref_boxes, 2e-4, "pred_boxes")
     assert_close(logits[:, :T], ref_logits[:, :T], 2e-4, "pred_logits")
+
+
+def test_full_size_gdino_swinb_matches_hf(device):
+    """The real architecture (Swin-B 384/window 12, BERT-base, 6+6 layers, 900 queries) at the network resolution the
+    pipeline feeds it, random weights; HF runs in fp32 on the same GPU."""
+    import time
+    from transformers.models.grounding_dino.modeling_grounding_dino import generate_masks_with_special_tokens_and_transfer_map
+    from ovmono3d_amd.gdino.detector import HashTokenizer
+    from ovmono3d_amd.gdino.model import GDinoConfig, GroundingDinoNative
+    from ovmono3d_amd.util.synth_gdino import synth_gdino_model
+    hf, sd = synth_gdino_model(5)
+    _patch_hf_to_upstream(hf)
+    hf = hf.to(device)
+    H, W = 532, 708
+    g = torch.Generator().manual_seed(2)
+    img = torch.randn(1, 3, H, W, generator=g).to(device)
+    ids = torch.tensor(HashTokenizer().encode("chair . dining table . sofa . potted plant . television . bookcase ."))
+    with torch.no_grad():
+        out = hf(pixel_values=img, input_ids=ids[None].to(device), return_dict=True)
+    _, p_hf = generate_masks_with_special_tokens_and_transfer_map(ids[None])
+    net = GroundingDinoNative(_ops(device), sd, GDinoConfig())
+    x = img[0].permute(1, 2, 0).reshape(H * W, 3).contiguous()
+    _, _, aux = net.forward(x, H, W, ids, position_ids=p_hf[0], return_aux=True)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(3):
+        net.forward(x, H, W, ids, position_ids=p_hf[0])
+    torch.cuda.synchronize()
+    print(f"native GroundingDINO Swin-B forward {H}x{W}: {(time.time() - t0) / 3 * 1e3:.1f} ms")
+    T = len(ids)
+    assert_close(aux["enc_vision"], out.encoder_last_hidden_state_vision[0], 1e-4, "encoder vision")
+    assert_close(aux["enc_text"], out.encoder_last_hidden_state_text[0], 1e-4, "encoder text")
+    # two-stage selection: same 900 proposals; the ORDER may differ between proposals whose scores tie to rounding, and the
+    # order matters downstream (slot i gets learned target i), so the decoder comparison below pins HF's order.
+    sc = out.enc_outputs_class[0].max(-1)[0]
+    hf_topk = torch.topk(sc, 900)[1]
+    mine, theirs = aux["topk"].cpu(), hf_topk.cpu()
+    assert sorted(mine.tolist()) == sorted(theirs.tolist())
+    swapped = mine != theirs
+    assert int(swapped.sum()) <= 20
+    assert ((sc[mine[swapped].to(device)] - sc[theirs[swapped].to(device)]).abs() <= 1e-4 * sc.abs().max()).all()
+    logits, boxes = net.forward(x, H, W, ids, position_ids=p_hf[0], force_topk=hf_topk)
+    assert_close(boxes, out.pred_boxes[0], 3e-4, "pred_boxes")
+    assert_close(logits[:, :T], out.logits[0][:, :T], 3e-4, "pred_logits")

@@ -106,6 +106,7 @@ def test_gdino_head_requires_category_list_and_detector():
         device = torch.device("cpu")
     h = ROIHeads3DGDINO.__new__(ROIHeads3DGDINO)
     h.training, h.detector, h.loss_w_3d, h.engine = False, None, 1.0, FakeEngine()
+    h._gdino_cfg = build_cfg()                       # default GDINO_WEIGHTS path does not exist here -> loud failure
     il = ImageList(None, [(10, 10)])
     with pytest.raises(NameError):
         h.forward(il, {}, None, [], [1.0], None, category_list=None)
