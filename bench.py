@@ -8,8 +8,9 @@ A "step" = one pass of the hot path (preprocess -> DINOv2 ViT + SFP -> ROIAlign 
 are already resident in HBM. Workload = BASELINE.json configs[1]: DINOv2-L/14 + SFP, batch 1, a
 512x512x3 synthetic image at network resolution 532x532 (ResizeShortestEdge(532) is host data feeding,
 outside the path) on the reference's 896x896 SQUARE_PAD canvas (T = 4097 tokens). The 2D boxes come from
-the oracle-2D branch (32 boxes/image, SURVEY.md §8d mode A): the native GroundingDINO network that
-ROIHeads3DGDINO would call is not built yet.
+ROIHeads3DGDINO's native GroundingDINO network (Swin-B + BERT-base + 6/6 deformable transformer, 900 queries,
+random-init weights, 6 prompted categories) -> phrase scores -> NMS; `--proposals oracle2d` measures the
+oracle-2D branch instead (32 given boxes/image, SURVEY.md §8d mode A).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP
 events on the launch stream) and `cpu_baseline` (the fp32 torch CPU oracle on the host cores, rank 0,
@@ -51,7 +52,8 @@ def main():
     ap.add_argument("--model", default="vitl14")
     ap.add_argument("--canvas", type=int, default=896)
     ap.add_argument("--net-res", type=int, default=532)
-    ap.add_argument("--boxes", type=int, default=32)
+    ap.add_argument("--boxes", type=int, default=32, help="boxes per image for --proposals oracle2d")
+    ap.add_argument("--proposals", default="gdino", choices=["gdino", "oracle2d"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra one-pass fp16 measurement")
     args = ap.parse_args()
@@ -95,17 +97,45 @@ def main():
             w = 32 + torch.rand(args.boxes, generator=g) * 96
             h = 32 + torch.rand(args.boxes, generator=g) * 96
             boxes = torch.stack([x1, y1, x1 + w, y1 + h], 1)
-            out.append({"image": img, "height": oh, "width": ow, "K": K, "image_id": i,
-                        "oracle2D": {"gt_bbox2D": boxes, "gt_classes": torch.randint(0, 50, (args.boxes,), generator=g),
-                                     "gt_scores": 0.3 + 0.7 * torch.rand(args.boxes, generator=g)}})
+            d = {"image": img, "height": oh, "width": ow, "K": K, "image_id": i}
+            if use_gdino:
+                d["category_list"] = list(CATEGORIES)
+            else:
+                d["oracle2D"] = {"gt_bbox2D": boxes, "gt_classes": torch.randint(0, 50, (args.boxes,), generator=g),
+                                 "gt_scores": 0.3 + 0.7 * torch.rand(args.boxes, generator=g)}
+            out.append(d)
         return out
 
     sd = synth_state_dict(args.model, seed=0)
+    use_gdino = args.proposals == "gdino"
+    CATEGORIES = ("chair", "dining table", "sofa", "potted plant", "television", "bookcase")
+    gd_hf = gd_sd = None
+    gd_events = []
+    if use_gdino:
+        if B != 1:
+            raise SystemExit("ROIHeads3DGDINO processes one image per batch (reference rcnn3d.py:108): use --batch 1")
+        from ovmono3d_amd.gdino.detector import HashTokenizer, NativeGroundingDino
+        from ovmono3d_amd.util.synth_gdino import synth_gdino_model
+        gd_hf, gd_sd = synth_gdino_model(0)
 
     def run(precision, steps, warmup, profile):
-        cfg = build_cfg(args.model, args.canvas, precision, max_batch=B, max_rois=max(64, args.boxes))
+        cfg = build_cfg(args.model, args.canvas, precision, max_batch=B, max_rois=1000 if use_gdino else max(64, args.boxes),
+                        roi_heads="ROIHeads3DGDINO" if use_gdino else "ROIHeads3D")
         model = build_model(cfg, device=dev)
         model.load_state_dict(sd)
+        if use_gdino:
+            det = NativeGroundingDino(dev, gd_sd, HashTokenizer(), cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD,
+                                      precision=3 if precision == "f16x3" else 1)
+            gd_events.clear()
+
+            def timed_detector(image, caption):                 # device time of the GroundingDINO network per call
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = det(image, caption)
+                e1.record()
+                gd_events.append((e0, e1))
+                return r
+            model.roi_heads.detector = timed_detector
         host_inputs = make_inputs(1000 + rank)
         inputs = []
         for d in host_inputs:                      # images resident in HBM before the timed region
@@ -157,6 +187,9 @@ def main():
     kernels = {k: {"ms_per_step": round(prof[k][0] / args.steps, 4), "launches_per_step": prof[k][1] // args.steps,
                    **({"tflops": round(kf[k] * B * prof[k][1] / (prof[k][0] * 1e-3) / 1e12, 2)} if k in kf and prof[k][0] > 0 else {})}
                for k in prof}
+    if use_gdino and gd_events:
+        ev = gd_events[-args.steps:]
+        kernels["gdino_network"] = {"ms_per_step": round(sum(a.elapsed_time(b) for a, b in ev) / len(ev), 4), "launches_per_step": None}
     total_flops = vit_flops(T, D, L, G * G) * B
     e2e_tflops = total_flops * args.steps / dt / 1e12
 
@@ -183,18 +216,41 @@ def main():
         ncores = int(os.environ.get("OVM_CPU_THREADS", min(avail, 16)))
         torch.set_num_threads(ncores)
         P = oracle_params(cfg)
+        cpu_in = [dict(host_inputs[0])]
+        if use_gdino:
+            # CPU leg of the GroundingDINO branch: the Hugging Face port (fp32, eager) as the stand-in for the upstream
+            # network the reference calls, + the oracle's restatement of the reference glue (oracle/gdino_glue.py)
+            from oracle import gdino_glue as og
+            tok = HashTokenizer()
+            caption, cap_list = og.build_caption(list(CATEGORIES))
+            ids = tok.encode(caption)
+            spans = og.phrase_spans(ids, [tok.encode(c, add_special_tokens=False) for c in cap_list])
+            mean = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1)
+            std = torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1)
+            cpu_in[0].pop("category_list")
+
+            def cpu_gdino():
+                x = ((cpu_in[0]["image"].float() - mean) / std)[[2, 1, 0]]
+                o = gd_hf(pixel_values=x[None], input_ids=torch.tensor(ids)[None], return_dict=True)
+                lg = torch.full((o.logits.shape[1], 256), float("-inf"))
+                lg[:, :len(ids)] = o.logits[0][:, :len(ids)]
+                bx, sc, cl = og.gdino_postprocess(lg, o.pred_boxes[0], spans, cap_list, [[c] for c in CATEGORIES], x.shape[1:])
+                cpu_in[0]["oracle2D"] = {"gt_bbox2D": bx, "gt_classes": cl, "gt_scores": sc}
         with torch.no_grad():
             t0 = time.perf_counter()
             nimg = 0
             while True:
-                inference(sd, host_inputs[:1], P)
+                if use_gdino:
+                    cpu_gdino()
+                inference(sd, cpu_in, P)
                 nimg += 1
                 el = time.perf_counter() - t0
                 if el > 12.0 or nimg >= 3:
                     break
         cpu_baseline = {"value": round(nimg / el, 4), "unit": "images/sec", "cores": ncores, "kind": "port",
-                        "sample": f"{nimg} image(s) of the same workload through oracle/ (fp32 torch CPU restatement), "
-                                  f"{el:.1f} s, torch threads={ncores}"}
+                        "sample": f"{nimg} image(s) of the same workload through oracle/ (fp32 torch CPU restatement"
+                                  + (" + Hugging Face GroundingDINO fp32 on CPU for the text-prompted boxes" if use_gdino else "")
+                                  + f"), {el:.1f} s, torch threads={ncores}"}
 
     if rank == 0:
         line = {
@@ -202,10 +258,12 @@ def main():
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16x3" if args.precision == "f16x3" else "f16", "data": "synthetic",
-            "config": {"workload": f"DINOv2 {args.model} + SFP + oracle-2D boxes ({args.boxes}/img) + ROIAlign + CubeHead + decode, "
-                                   f"batch {B}/GPU, 512x512 synthetic -> network res {args.net_res} -> canvas {args.canvas} (T={T}), "
-                                   f"random-init weights (seed 0)",
-                       "proposal_source": "oracle2D (native GroundingDINO for ROIHeads3DGDINO not built yet)",
+            "config": {"workload": f"DINOv2 {args.model} + SFP + "
+                                   + ("ROIHeads3DGDINO (native GroundingDINO Swin-B/BERT-base, 900 queries, 6 categories -> NMS)" if use_gdino
+                                      else f"oracle-2D boxes ({args.boxes}/img)")
+                                   + f" + ROIAlign + CubeHead + decode, batch {B}/GPU, 512x512 synthetic -> network res {args.net_res} "
+                                     f"-> canvas {args.canvas} (T={T}), random-init weights (seed 0)",
+                       "proposal_source": "ROIHeads3DGDINO native GroundingDINO" if use_gdino else "oracle2D",
                        "precision": args.precision, "parallelism": f"dp{world} (image-sharded, no data-path collective)",
                        "ap3d_delta": "not measurable offline (no Omni3D data / checkpoint); tensor parity vs CPU oracle <=1e-3"},
             "images_per_sec_per_gpu": round(value / world, 3),

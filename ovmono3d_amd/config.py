@@ -261,5 +261,6 @@ def get_cfg_defaults(cfg: CfgNode) -> CfgNode:
     cfg.MODEL.AMD = CfgNode(dict(GEMM_PRECISION="f16x3", MAX_BATCH=1, MAX_ROIS=1000,
                                  # GroundingDINO branch of ROIHeads3DGDINO: checkpoint (the reference hard-codes this path,
                                  # roi_heads_gdino.py:87-91; "synthetic://gdino?seed=N" = random init) and bert-base-uncased vocab.txt
-                                 GDINO_WEIGHTS="./checkpoints/groundingdino_swinb_cogcoor.pth", BERT_VOCAB=""))
+                                 GDINO_WEIGHTS="./checkpoints/groundingdino_swinb_cogcoor.pth", BERT_VOCAB="",
+                                 GDINO_OVERLAP=True, GDINO_GRAPHS=True))
     return cfg

@@ -397,5 +397,12 @@ int launch_gemm(const GemmParams& p, int npass, int epi, int amode, hipStream_t 
 void gemm_set_force_bm(int bm);
 void gemm_set_tail_rows(int on);
 void gemm_set_stages(int n);
+// gemm_small.hip: fp32-A latency-oriented kernel used by the generic linear op
+bool gemm_small_supported(const float* A, int lda, int K);
+int launch_gemm_small(const float* A, int lda, int M, int K, const half_t* Whi, const half_t* Wlo, int N, int Kpad, const float* bias, int act,
+                      const float* R, int ldr, float* C, int ldc, int npass, hipStream_t s);
+void gemm_small_set(int target_blocks, int max_ksplit);
+void gemm_small_set_stages(int n);
+void glinear_set_small_max_tiles(int t);
 
 }  // namespace ovm

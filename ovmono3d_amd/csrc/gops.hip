@@ -16,6 +16,7 @@ namespace {
 // ---- scratch (grown on demand; one stream / one thread per process, like the rest of the library) ----
 struct Scratch { void* p = nullptr; size_t cap = 0; };
 Scratch g_s[2];
+long g_small_max_tiles = -1;      // -1: built-in heuristic
 void* scratch(int i, size_t bytes) {
   if (g_s[i].cap < bytes) {
     if (g_s[i].p) { (void)hipDeviceSynchronize(); (void)hipFree(g_s[i].p); }
@@ -67,25 +68,43 @@ __global__ __launch_bounds__(256) void ln_generic_kernel(const float* __restrict
 // batch index z = z1 * nb2 + z2 with independent strides per level (e.g. window x head)
 __global__ __launch_bounds__(256) void bmm_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ Cm,
                                                   int M, int N, int K, int lda, int ldb, int ldc, long sA, long sB, long sC,
-                                                  int nb2, long sA2, long sB2, long sC2, int transB, float alpha) {
+                                                  int nb2, long sA2, long sB2, long sC2, int transB, float alpha, int tiles_n, int kchunk,
+                                                  float* __restrict__ part) {
   __shared__ float As[16][17], Bs[16][17];
+  const int ks = blockIdx.x / tiles_n, bx = blockIdx.x - ks * tiles_n;            // split-K slice (kchunk % 16 == 0)
+  const int kbeg = ks * kchunk, kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
   const int z1 = blockIdx.z / nb2, z2 = blockIdx.z - z1 * nb2;
   const float* a = A + (size_t)z1 * sA + (size_t)z2 * sA2; const float* b = Bm + (size_t)z1 * sB + (size_t)z2 * sB2;
   float* c = Cm + (size_t)z1 * sC + (size_t)z2 * sC2;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
+  const int m = blockIdx.y * 16 + ty, n = bx * 16 + tx;
   float acc = 0.f;
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    As[ty][tx] = (m < M && k0 + tx < K) ? a[(size_t)m * lda + k0 + tx] : 0.f;
-    const int nn = blockIdx.x * 16 + ty;                                      // for the transposed load
-    if (transB) Bs[tx][ty] = (nn < N && k0 + tx < K) ? b[(size_t)nn * ldb + k0 + tx] : 0.f;   // Bs[k][n]
-    else Bs[ty][tx] = (k0 + ty < K && n < N) ? b[(size_t)(k0 + ty) * ldb + n] : 0.f;
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    As[ty][tx] = (m < M && k0 + tx < kend) ? a[(size_t)m * lda + k0 + tx] : 0.f;
+    const int nn = bx * 16 + ty;                                              // for the transposed load
+    if (transB) Bs[tx][ty] = (nn < N && k0 + tx < kend) ? b[(size_t)nn * ldb + k0 + tx] : 0.f;   // Bs[k][n]
+    else Bs[ty][tx] = (k0 + ty < kend && n < N) ? b[(size_t)(k0 + ty) * ldb + n] : 0.f;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc = fmaf(As[ty][k], Bs[k][tx], acc);
     __syncthreads();
   }
-  if (m < M && n < N) c[(size_t)m * ldc + n] = alpha * acc;
+  if (m < M && n < N) {
+    if (part) part[(((size_t)ks * gridDim.z + blockIdx.z) * M + m) * N + n] = acc;
+    else c[(size_t)m * ldc + n] = alpha * acc;
+  }
+}
+
+// sums the split-K partials of bmm_kernel: part [ksplit][nz][M][N] -> c (batch strides as in bmm_kernel)
+__global__ void bmm_reduce_kernel(const float* __restrict__ part, float* __restrict__ Cm, int ksplit, int nz, int M, int N, int ldc, long sC,
+                                  int nb2, long sC2, float alpha) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)nz * M * N) return;
+  const int n = (int)(i % N); const int m = (int)((i / N) % M); const int z = (int)(i / ((long)M * N));
+  float acc = 0.f;
+  for (int ks = 0; ks < ksplit; ++ks) acc += part[(size_t)ks * nz * M * N + i];
+  const int z1 = z / nb2, z2 = z - z1 * nb2;
+  Cm[(size_t)z1 * sC + (size_t)z2 * sC2 + (size_t)m * ldc + n] = alpha * acc;
 }
 
 // x[r][:] = softmax(x[r][:] + bias[(r / bias_div) % bias_rows][:]) ; one wave per row
@@ -240,6 +259,8 @@ inline dim3 g1(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)
 
 }  // namespace
 
+namespace ovm { void glinear_set_small_max_tiles(int t) { g_small_max_tiles = t; } }
+
 extern "C" {
 
 int ovm_g_pack_weight(const float* w, int32_t N, int32_t K, int32_t Kpad, uint16_t* hi, uint16_t* lo, ovm_stream_t stream) {
@@ -254,6 +275,12 @@ int ovm_g_linear(const float* x, int32_t ldx, int32_t M, int32_t K, const uint16
                  ovm_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if (M <= 0) return OVM_OK;
+  // small / mid-size problems: fp32-A 64x64-tile kernel (splits x in registers, split-K on thin grids); very large grids keep
+  // the 128x128 LDS-DMA kernel behind a split pre-pass
+  const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  const long small_max = g_small_max_tiles >= 0 ? g_small_max_tiles : (K <= 512 ? 100 : 64);     // measured crossover (scratch/bench_linear.py)
+  if (tiles128 <= small_max && gemm_small_supported(x, ldx, K))
+    return launch_gemm_small(x, ldx, M, K, (const half_t*)w_hi, (const half_t*)w_lo, N, Kpad, bias, act, residual, ldr, y, ldy, precision, s);
   const size_t ne = (size_t)M * Kpad;
   half_t* ahi = (half_t*)scratch(0, ne * 2);
   half_t* alo = (half_t*)scratch(1, ne * 2);
@@ -282,12 +309,32 @@ int ovm_g_bmm2(const float* a, const float* b, float* c, int32_t nb1, int32_t nb
                ovm_stream_t stream) {
   if (nb1 <= 0 || nb2 <= 0 || M <= 0 || N <= 0) return OVM_OK;
   const long nz = (long)nb1 * nb2;
+  const int tiles_n = (N + 15) / 16;
+  // long reductions on a thin grid (text <- image attention: 16 x 6015 per head): split K over workgroups
+  const long blocks = (long)tiles_n * ((M + 15) / 16) * nz;
+  if (blocks < 512 && K >= 1024 && nz <= 65535) {
+    int ksplit = (int)((1024 + blocks - 1) / blocks);
+    if (ksplit > K / 128) ksplit = K / 128;
+    if (ksplit > 64) ksplit = 64;
+    if (ksplit > 1) {
+      const int kchunk = ((K + ksplit - 1) / ksplit + 15) / 16 * 16;
+      ksplit = (K + kchunk - 1) / kchunk;
+      float* part = (float*)scratch(0, (size_t)ksplit * nz * M * N * sizeof(float));
+      if (!part) return OVM_ERR_HIP;
+      hipLaunchKernelGGL(bmm_kernel, dim3(tiles_n * ksplit, (M + 15) / 16, (unsigned)nz), dim3(256), 0, (hipStream_t)stream, a, b, c, M, N, K,
+                         lda, ldb, ldc, (long)sA1, (long)sB1, (long)sC1, nb2, (long)sA2, (long)sB2, (long)sC2, transB, alpha, tiles_n, kchunk, part);
+      const long n_out = nz * M * N;
+      hipLaunchKernelGGL(bmm_reduce_kernel, g1(n_out), dim3(256), 0, (hipStream_t)stream, part, c, ksplit, (int)nz, M, N, ldc, (long)sC1, nb2,
+                         (long)sC2, alpha);
+      return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+    }
+  }
   for (long z0 = 0; z0 < nz; z0 += 65535 / nb2 * nb2) {          // grid.z limit; chunks keep z2 aligned
     const long cnt = (nz - z0 < (long)(65535 / nb2 * nb2)) ? nz - z0 : (long)(65535 / nb2 * nb2);
     const long o1 = z0 / nb2;
     hipLaunchKernelGGL(bmm_kernel, dim3((N + 15) / 16, (M + 15) / 16, (unsigned)cnt), dim3(256), 0, (hipStream_t)stream, a + o1 * sA1,
                        b + o1 * sB1, c + o1 * sC1, M, N, K, lda, ldb, ldc, (long)sA1, (long)sB1, (long)sC1, nb2, (long)sA2, (long)sB2,
-                       (long)sC2, transB, alpha);
+                       (long)sC2, transB, alpha, tiles_n, (K + 15) / 16 * 16, (float*)nullptr);
   }
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }

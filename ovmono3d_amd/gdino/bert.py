@@ -58,18 +58,19 @@ class BertEncoder:
             i += 1
 
     def forward(self, input_ids: torch.Tensor, attn_mask: torch.Tensor, position_ids: torch.Tensor,
-                token_type_ids: torch.Tensor = None) -> torch.Tensor:
+                token_type_ids: torch.Tensor = None, bias: torch.Tensor = None) -> torch.Tensor:
         """input_ids [T] int64; attn_mask bool [T,T]; returns last hidden state [T, D] (device fp32)."""
         o = self.ops
         T, D, H = int(input_ids.shape[0]), self.D, self.heads
         dh = D // H
         ids = input_ids.to(torch.int32).view(T, 1)
-        tt = (token_type_ids if token_type_ids is not None else torch.zeros_like(input_ids)).to(torch.int32).view(T, 1)
+        tt = (token_type_ids if token_type_ids is not None else torch.zeros_like(ids)).to(torch.int32).view(T, 1)
         x = o.gather_rows(self.word, ids)
         x = o.add(x, o.gather_rows(self.pos, position_ids.to(torch.int32).view(T, 1)))
         x = o.add(x, o.gather_rows(self.typ, tt))
         x = o.layernorm(x, self.eg, self.eb, 1e-12)
-        bias = torch.where(attn_mask, 0.0, torch.finfo(torch.float32).min).to(o.dev, torch.float32).contiguous()   # mask -> additive
+        if bias is None:
+            bias = torch.where(attn_mask, 0.0, torch.finfo(torch.float32).min).to(o.dev, torch.float32).contiguous()   # mask -> additive
         for ly in self.layers:
             qkv = o.linear(x, ly["qkv"])                                             # [T, 3D]
             s = o.empty(H, T, T)

@@ -175,6 +175,7 @@ class GroundingDinoNative:
             e_wh[2 + j % 2, j] = 0.5 / c.n_points
         self.e_ctr, self.e_wh = f(e_ctr), f(e_wh)
         self._shape_cache = {}
+        self._caption_cache = {}
 
     # ---- helpers --------------------------------------------------------------------------------
     def _mlp(self, x, layers):
@@ -222,14 +223,24 @@ class GroundingDinoNative:
         o, c = self.o, self.cfg
         D = c.d_model
         aux = {}
-        # -- text
-        mask, pos_ids = masks_and_position_ids(input_ids)
-        if position_ids is not None:
-            pos_ids = position_ids
+        # -- text. Everything derived from the caption alone is uploaded once per caption (no host->device traffic on
+        # later calls, which also keeps the forward capturable into a HIP graph)
         T = int(input_ids.shape[0])
-        text = o.linear(self.bert.forward(input_ids, mask, pos_ids), self.text_proj)                      # [T, D]
-        text_bias = torch.where(mask, 0.0, torch.finfo(torch.float32).min).to(o.dev, torch.float32).contiguous()
-        text_pos = o.sine_embed(pos_ids.to(torch.float32).view(T, 1).to(o.dev), D, 10000.0)                # [T, D]
+        ck = (tuple(int(i) for i in input_ids.tolist()), None if position_ids is None else tuple(int(i) for i in position_ids.tolist()))
+        cap = self._caption_cache.get(ck)
+        if cap is None:
+            mask, pos_ids = masks_and_position_ids(input_ids)
+            if position_ids is not None:
+                pos_ids = position_ids
+            cap = dict(ids=input_ids.to(o.dev, torch.int32).view(T, 1), mask=mask.to(o.dev), pos=pos_ids.to(o.dev, torch.int32).view(T, 1),
+                       bias=torch.where(mask, 0.0, torch.finfo(torch.float32).min).to(o.dev, torch.float32).contiguous(),
+                       pos_f=pos_ids.to(torch.float32).view(T, 1).to(o.dev))
+            if len(self._caption_cache) > 64:
+                self._caption_cache.clear()
+            self._caption_cache[ck] = cap
+        text = o.linear(self.bert.forward(cap["ids"], cap["mask"], cap["pos"], bias=cap["bias"]), self.text_proj)       # [T, D]
+        text_bias = cap["bias"]
+        text_pos = o.sine_embed(cap["pos_f"], D, 10000.0)                                                # [T, D]
         # -- image features, 4 levels
         feats = self.swin.forward(img_nhwc, H, W)
         srcs, shapes = [], []

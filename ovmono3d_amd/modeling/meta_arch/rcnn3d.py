@@ -86,6 +86,8 @@ class RCNN3D:
         im_scales_ratio = [info["height"] / s[0] for info, s in zip(batched_inputs, images.image_sizes)]   # :92
         Ks = [torch.FloatTensor(np.asarray(info["K"], dtype=np.float32)) for info in batched_inputs]      # :95
         images.fuse_postprocess = bool(do_postprocess)
+        if hasattr(self.roi_heads, "prefetch") and "oracle2D" not in batched_inputs[0] and "category_list" in batched_inputs[0]:
+            self.roi_heads.prefetch(images, batched_inputs[0]["category_list"])       # side stream, overlaps the backbone
         features = self.backbone(images, prompt_depth=prompt_depth)                                        # :97
         if isinstance(batched_inputs, list) and np.any(["oracle2D" in b for b in batched_inputs]):         # :100-102
             oracles = [b["oracle2D"] for b in batched_inputs]

@@ -30,6 +30,9 @@ def test_generic_ops(device):
     assert_close(o.bmm(a, bb, True, 0.5), 0.5 * (a.cpu() @ bb.cpu().transpose(1, 2)), 2e-6, "bmm^T")
     bn = torch.randn(3, 20, 31, generator=g).to(device)
     assert_close(o.bmm(a, bn, False), a.cpu() @ bn.cpu(), 2e-6, "bmm")
+    ak = torch.randn(4, 16, 6015, generator=g).to(device)                 # long reduction on a thin grid -> split-K route
+    bk = torch.randn(4, 6015, 40, generator=g).to(device)
+    assert_close(o.bmm(ak, bk, False), (ak.cpu().double() @ bk.cpu().double()).float(), 2e-6, "bmm split-K")
     s = torch.randn(4 * 10, 33, generator=g).to(device)
     bias = torch.randn(10, 33, generator=g).to(device)
     bias[2, 5] = float("-inf")
@@ -45,6 +48,36 @@ def test_generic_ops(device):
     idx = torch.tensor([[0, 3], [-1, 8], [2, 2]], dtype=torch.int32)
     got = o.gather_rows(src, idx).cpu()
     assert torch.equal(got[0], torch.cat([src[0], src[3]]).cpu()) and torch.all(got[1, :6] == 0) and torch.equal(got[1, 6:], src[8].cpu())
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 768, 3072), (900, 256, 256), (900, 4, 256), (7, 10, 36), (130, 66, 100), (1156, 512, 2048),
+                                   (6015, 256, 1024), (81, 256, 9216), (20736, 128, 128)])
+@pytest.mark.parametrize("precision", [3, 1])
+def test_linear_shapes(device, M, N, K, precision):
+    """The generic projection over the shapes the GroundingDINO branch issues: thin (text), split-K (long K on a small
+    grid), ragged M / N / K, and both routes (fp32-A 64x64 kernel, 128x128 LDS-DMA kernel behind a split pre-pass)."""
+    from ovmono3d_amd import lib as _lib
+    o = _ops(device, precision)
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(device)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).to(device)
+    W = o.pack(w, b)
+    ref = torch.relu(x.cpu().double() @ w.double().T + b.double()) + res.cpu().double()
+    tol = max(2e-6, 3e-8 * K ** 0.5) if precision == 3 else 2e-3
+    try:
+        for route in (1 << 30, 0):                 # all problems on the small kernel / none
+            assert _lib.load().ovm_tune_set(b"glin_small_max_tiles", route) == 0
+            assert_close(o.linear(x, W, act=1, residual=res), ref.float(), tol, f"linear route {route}")
+            assert_close(o.linear(x, W), (x.cpu().double() @ w.double().T + b.double()).float(), tol, f"linear plain route {route}")
+        for stages in (2, 1):
+            _lib.load().ovm_tune_set(b"glin_small_max_tiles", 1 << 30)
+            _lib.load().ovm_tune_set(b"glin_stages", stages)
+            assert_close(o.linear(x, W, act=1, residual=res), ref.float(), tol, f"linear stages {stages}")
+    finally:
+        _lib.load().ovm_tune_set(b"glin_small_max_tiles", -1)
+        _lib.load().ovm_tune_set(b"glin_stages", 1)
 
 
 def test_msdeform_and_sine_embed_match_hf(device):
@@ -243,3 +276,31 @@ def test_full_size_gdino_swinb_matches_hf(device):
     logits, boxes = net.forward(x, H, W, ids, position_ids=p_hf[0], force_topk=hf_topk)
     assert_close(boxes, out.pred_boxes[0], 3e-4, "pred_boxes")
     assert_close(logits[:, :T], out.logits[0][:, :T], 3e-4, "pred_logits")
+
+
+def test_detector_graph_replay_matches_eager(device):
+    """NativeGroundingDino captures the forward into a HIP graph on the second sight of an (image size, caption) pair; the
+    replay on new pixels must equal the eager forward on those pixels bit for bit."""
+    from ovmono3d_amd.gdino.detector import HashTokenizer, NativeGroundingDino
+    from ovmono3d_amd.gdino.model import GDinoConfig
+    hf, cfg = _small_hf_gdino()
+    ncfg = GDinoConfig(d_model=64, enc_layers=2, dec_layers=2, heads=4, ffn_dim=128, num_queries=30, bert_heads=2, swin_embed=32,
+                       swin_depths=(2, 2, 2, 2), swin_heads=(1, 2, 4, 8), swin_window=12)
+    sd = hf.state_dict()
+    mean, std = [103.53, 116.28, 123.675], [57.375, 57.12, 58.395]
+
+    class Tok(HashTokenizer):
+        def _id(self, w):
+            return super()._id(w) % 1900 + 50 if w not in (".", "?") else super()._id(w)
+    eager = NativeGroundingDino(device, sd, Tok(), mean, std, cfg=ncfg, use_graphs=False)
+    graphed = NativeGroundingDino(device, sd, Tok(), mean, std, cfg=ncfg, use_graphs=True)
+    g = torch.Generator().manual_seed(3)
+    caption = "chair . dining table ."
+    for i in range(4):
+        im = torch.randint(0, 256, (3, 96, 132), dtype=torch.uint8, generator=g).to(device)
+        a = eager(im, caption)
+        b = graphed(im, caption)
+        assert torch.equal(a["pred_boxes"], b["pred_boxes"]) and torch.equal(a["pred_logits"], b["pred_logits"]), i
+    assert len(graphed._graphs) == 1
+    im2 = torch.randint(0, 256, (3, 100, 132), dtype=torch.uint8, generator=g).to(device)      # another size: eager first
+    assert torch.equal(eager(im2, caption)["pred_boxes"], graphed(im2, caption)["pred_boxes"])
