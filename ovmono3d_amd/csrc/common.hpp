@@ -35,6 +35,18 @@ __device__ __forceinline__ half_t cvt_f16_rn(float x) {
   return __builtin_bit_cast(half_t, (uint16_t)(r & 0xFFFFu));
 }
 
+// Same conversion for operands that do NOT come straight out of a transcendental instruction (loads, adds, FMAs): no
+// hazard nop needed, and not volatile, so the scheduler may interleave it with MFMAs and memory instructions.
+__device__ __forceinline__ half_t cvt_f16_rn_nt(float x) {
+  uint32_t r;
+  asm("v_cvt_f16_f32 %0, %1" : "=v"(r) : "v"(x));
+  return __builtin_bit_cast(half_t, (uint16_t)(r & 0xFFFFu));
+}
+__device__ __forceinline__ void split_f16_nt(float x, half_t& hi, half_t& lo) {
+  hi = cvt_f16_rn_nt(x);
+  lo = cvt_f16_rn_nt(x - (float)hi);
+}
+
 __device__ __forceinline__ void split_f16(float x, half_t& hi, half_t& lo) {
   hi = cvt_f16_rn(x);
   lo = cvt_f16_rn(x - (float)hi);

@@ -6,6 +6,7 @@ namespace ovm {
 static int g_force_bm = 0;
 static int g_tail_rows = 1;
 static int g_force_stages = 0;
+
 void gemm_set_stages(int n) { g_force_stages = n; }
 void gemm_set_force_bm(int bm) { g_force_bm = bm; }
 void gemm_set_tail_rows(int on) { g_tail_rows = on; }
@@ -39,6 +40,32 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 
+template <int NPASS, int BK, int NS, int EPI, int AMODE>
+static int launch_ws(const GemmParams& p, hipStream_t s) {
+  constexpr int smem = NS * (128 + 128) * BK * 2 * ((NPASS == 3) ? 2 : 1);
+  if (p.K % BK != 0) return OVM_ERR_SHAPE;
+  GemmParams q = p;
+  q.M_total = p.M; q.tail_begin = p.M; q.main_tiles = 0;
+  int tail_blocks = 0;
+  const int tail = p.M % 128;
+  if (g_tail_rows && tail > 0 && tail <= 8 && p.M > 128 && p.K % 64 == 0) {
+    q.tail_begin = p.M - tail;
+    q.M = q.tail_begin;
+    tail_blocks = tail * ((p.N + 4 * 8 - 1) / (4 * 8));        // 8 waves per workgroup, 4 columns per wave
+  }
+  const int tiles_m = (q.M + 127) / 128;
+  const int tiles_n = (p.N + 127) / 128;
+  q.main_tiles = tiles_m * tiles_n;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_ws_kernel<NPASS, BK, NS, EPI, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return OVM_ERR_HIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_ws_kernel<NPASS, BK, NS, EPI, AMODE>), dim3(q.main_tiles + tail_blocks), dim3(512), smem, s, q);
+  return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
+
 // Tile height. Measured on MI355X at the ViT-L shapes (M = 4097; N, K in {1024, 3072, 4096}; profiles/r01):
 // 128 rows with two LDS stages (2-3 workgroups per CU) beats 256 rows and the 3-stage ring everywhere, so that
 // is the default; the other variants stay selectable for tuning (ovm_tune_set "gemm_bm" / "gemm_stages").
@@ -51,7 +78,13 @@ template <int EPI, int AMODE>
 static int launch_prec(const GemmParams& p, int npass, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return OVM_OK;
   const int bm = pick_bm(p);
-  const int st = g_force_stages ? g_force_stages : 2;
+  // Default: up to three rounds of tiles (<= 768 on 256 CUs) run on the wave-specialised kernel (one workgroup per CU, no DMA
+  // issue or global-memory waits in the MFMA waves: +7..+16 % at the ViT-L qkv / proj / fc2 shapes); larger grids keep the
+  // symmetric two-workgroups-per-CU kernel, whose co-resident workgroup hides the per-tile prologue and epilogue (fc1).
+  const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  const int st = g_force_stages ? g_force_stages : (tiles <= 768 ? 6 : 2);
+  if (st == 5) return npass == 3 ? launch_ws<3, 32, 4, EPI, AMODE>(p, s) : launch_ws<1, 64, 4, EPI, AMODE>(p, s);
+  if (st == 6) return npass == 3 ? launch_ws<3, 32, 3, EPI, AMODE>(p, s) : launch_ws<1, 64, 3, EPI, AMODE>(p, s);
   if (npass == 3) {
     if (bm == 256) return st == 3 ? launch_one<3, 32, 256, 3, EPI, AMODE>(p, s) : launch_one<3, 32, 256, 2, EPI, AMODE>(p, s);
     return st == 3 ? launch_one<3, 32, 128, 3, EPI, AMODE>(p, s) : launch_one<3, 32, 128, 2, EPI, AMODE>(p, s);

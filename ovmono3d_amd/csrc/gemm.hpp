@@ -338,6 +338,223 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Wave-specialised variant: 128 x 128 tile, 8 waves. Waves 4-7 (one per SIMD) only move operands: they keep NS-1
+// k-tiles of LDS-DMA in flight through an NS-slot ring and publish a tile with a counted vmcnt wait + one
+// s_barrier per k-step. Waves 0-3 (one per SIMD, 64 x 64 each) only read fragments and issue MFMAs; they fetch the
+// fragments of tile t+1 into a second register set right after the barrier that publishes it, i.e. under the MFMAs
+// of tile t. The MFMA stream of a SIMD is therefore never interrupted by DMA issue, address arithmetic or by
+// waiting for global memory, which is what bounded the symmetric kernel above (SQ_WAIT_ANY ~ 47 %).
+// One barrier per k-step is enough: barrier(t) says "tile t landed" to the consumers and "tile t-1 consumed"
+// (its slot may be refilled with tile t+NS-1) to the producers.
+// ---------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  __builtin_amdgcn_s_waitcnt((N & 0xF) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
+template <int NPASS, int BK, int NS, int EPI, int AMODE>
+__global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmParams p) {
+  if ((int)blockIdx.x >= p.main_tiles) { gemm_tail_body<NPASS, EPI, AMODE>(p, (int)blockIdx.x - p.main_tiles); return; }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = 128, NPW = 4;
+  constexpr int ROWB = BK * 2;
+  constexpr int PART_A = BM * ROWB, PART_W = 128 * ROWB;
+  constexpr int STAGE = (PART_A + PART_W) * ((NPASS == 3) ? 2 : 1);
+  constexpr int OFF_AH = 0, OFF_WH = PART_A, OFF_AL = PART_A + PART_W, OFF_WL = 2 * PART_A + PART_W;
+  constexpr int ROWS_PER_INSTR = 1024 / ROWB;
+  constexpr int CH = ROWB / 16;
+  constexpr int IA = BM / ROWS_PER_INSTR / NPW;
+  constexpr int IW = 128 / ROWS_PER_INSTR / NPW;
+  constexpr int PER_STAGE = (IA + IW) * ((NPASS == 3) ? 2 : 1);      // DMA pieces one producer wave issues per k-tile
+  static_assert(NS >= 3 && NS <= 4 && (NS - 2) * PER_STAGE < 64, "ring depth vs vmcnt range");
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = p.main_tiles / tiles_m;
+  int pid = xcd_remap(blockIdx.x, p.main_tiles);
+  constexpr int GROUP_M = 8;
+  const int in_group = GROUP_M * tiles_n;
+  const int gid = pid / in_group;
+  const int first_m = gid * GROUP_M;
+  const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+  const int tm = first_m + (pid % in_group) % gsz;
+  const int tn = (pid % in_group) / gsz;
+  const int m0 = tm * BM, n0 = tn * 128;
+  const int nk = p.K / BK;
+
+  if (wave >= 4) {
+    // ---------------- producers ----------------
+    const int pw = wave - 4;
+    uint32_t aoff[IA], woff[IW];
+#pragma unroll
+    for (int t = 0; t < IA; ++t) {
+      const int row = (pw + NPW * t) * ROWS_PER_INSTR + lane / CH;
+      const int chunk = swz_slot<BK>(row, lane % CH);
+      int m = m0 + row; if (m > p.M - 1) m = p.M - 1;
+      aoff[t] = a_row_offset<AMODE>(p, m) + chunk * 8;
+    }
+#pragma unroll
+    for (int t = 0; t < IW; ++t) {
+      const int row = (pw + NPW * t) * ROWS_PER_INSTR + lane / CH;
+      const int chunk = swz_slot<BK>(row, lane % CH);
+      woff[t] = (uint32_t)(n0 + row) * (uint32_t)p.K + chunk * 8;
+    }
+    auto stage = [&](int slot, int kt) {
+      char* base = smem + slot * STAGE;
+      const uint32_t ak = a_k_offset<AMODE>(p, kt * BK);
+      const uint32_t wk = (uint32_t)(kt * BK);
+#pragma unroll
+      for (int t = 0; t < IA; ++t) {
+        char* dst = base + (pw + NPW * t) * 1024;
+        glds16(p.Ahi + aoff[t] + ak, dst + OFF_AH);
+        if (NPASS == 3) glds16(p.Alo + aoff[t] + ak, dst + OFF_AL);
+      }
+#pragma unroll
+      for (int t = 0; t < IW; ++t) {
+        char* dst = base + (pw + NPW * t) * 1024;
+        glds16(p.Whi + woff[t] + wk, dst + OFF_WH);
+        if (NPASS == 3) glds16(p.Wlo + woff[t] + wk, dst + OFF_WL);
+      }
+    };
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+      if (t < nk) stage(t, t);
+    int slot_next = NS - 1;                                   // slot of tile kt + NS - 1
+    for (int kt = 0; kt < nk; ++kt) {
+      const int ahead = (nk - 1 - kt < NS - 2) ? nk - 1 - kt : NS - 2;    // tiles issued after tile kt
+      if (ahead >= 2) wait_vmcnt<2 * PER_STAGE>();
+      else if (ahead == 1) wait_vmcnt<PER_STAGE>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (kt + NS - 1 < nk) stage(slot_next, kt + NS - 1);
+      slot_next = (slot_next + 1 == NS) ? 0 : slot_next + 1;
+    }
+    __builtin_amdgcn_s_barrier();                             // ring drained: the consumers reuse it for the epilogue
+    return;
+  }
+
+  // ---------------- consumers ----------------
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int NF = 4 * (BK / 32);                            // fragments per operand part per k-tile
+  half8 ahA[NF], whA[NF], alA[NF], wlA[NF], ahB[NF], whB[NF], alB[NF], wlB[NF];
+  int oa[NF], ow[NF];
+#pragma unroll
+  for (int kk = 0; kk < BK / 32; ++kk)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ra = wm * 64 + i * 16 + fr, rw = wn * 64 + i * 16 + fr;
+      oa[kk * 4 + i] = ra * ROWB + swz_slot<BK>(ra, kk * 4 + fq) * 16;
+      ow[kk * 4 + i] = rw * ROWB + swz_slot<BK>(rw, kk * 4 + fq) * 16;
+    }
+#define OVM_WS_READ(S, base)                                                            \
+  _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                      \
+    ah##S[f] = *(const half8*)((base) + OFF_AH + oa[f]);                                \
+    wh##S[f] = *(const half8*)((base) + OFF_WH + ow[f]);                                \
+    if (NPASS == 3) {                                                                   \
+      al##S[f] = *(const half8*)((base) + OFF_AL + oa[f]);                              \
+      wl##S[f] = *(const half8*)((base) + OFF_WL + ow[f]);                              \
+    }                                                                                   \
+  }
+#define OVM_WS_MFMA(S)                                                                  \
+  _Pragma("unroll") for (int kk = 0; kk < BK / 32; ++kk)                                \
+  _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                      \
+  _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                    \
+    if (NPASS == 3) {                                                                   \
+      acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl##S[kk * 4 + ni], ah##S[kk * 4 + mi], acc[ni][mi], 0, 0, 0); \
+      acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh##S[kk * 4 + ni], al##S[kk * 4 + mi], acc[ni][mi], 0, 0, 0); \
+    }                                                                                   \
+    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh##S[kk * 4 + ni], ah##S[kk * 4 + mi], acc[ni][mi], 0, 0, 0);   \
+  }
+
+  __builtin_amdgcn_s_barrier();                               // barrier(0): tile 0 landed
+  OVM_WS_READ(A, smem)
+  // steady state, two k-tiles per trip, branch-free: publish-wait, fetch the next tile's fragments, run this tile's MFMAs.
+  // lgkmcnt(0) is issued as the builtin: inline asm is invisible to the compiler's wait-count pass, which would then
+  // re-wait for the freshly issued reads in front of the MFMAs.
+  int kt = 0, slot = 1;                                       // slot = ring slot of tile kt + 1
+  // sched_barrier(0) pins the order "all fragment reads of the next tile, then this tile's MFMAs": left alone the
+  // scheduler sinks the reads next to their uses (one trip later) and the MFMAs end up waiting for them.
+  for (; kt + 2 < nk; kt += 2) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);                       // tile kt sits in registers: its slot may be refilled
+    __builtin_amdgcn_s_barrier();                             // barrier(kt+1)
+    OVM_WS_READ(B, smem + slot * STAGE)
+    slot = (slot + 1 == NS) ? 0 : slot + 1;
+    __builtin_amdgcn_sched_barrier(0);
+    OVM_WS_MFMA(A)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();                             // barrier(kt+2)
+    OVM_WS_READ(A, smem + slot * STAGE)
+    slot = (slot + 1 == NS) ? 0 : slot + 1;
+    __builtin_amdgcn_sched_barrier(0);
+    OVM_WS_MFMA(B)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (kt + 1 < nk) {                                          // two tiles left
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    OVM_WS_READ(B, smem + slot * STAGE)
+    __builtin_amdgcn_sched_barrier(0);
+    OVM_WS_MFMA(A)
+    OVM_WS_MFMA(B)
+  } else {                                                    // one tile left
+    OVM_WS_MFMA(A)
+  }
+#undef OVM_WS_READ
+#undef OVM_WS_MFMA
+
+  // Epilogue through LDS: the MFMA layout gives a lane 4 columns of 16 different rows (64-byte, or for fp16 outputs
+  // 32-byte, runs per row). Each consumer stages its 64 x 64 fp32 tile in the drained ring and re-reads it row-major,
+  // so that 16 lanes cover one row (256 B fp32 / 128 B fp16 per row and instruction: whole cache lines).
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  constexpr int TLD = 68;                                      // padded row stride (floats): conflict-free both ways
+  float* tile = (float*)smem + wave * (64 * TLD);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+      *(f32x4*)(tile + (mi * 16 + fr) * TLD + ni * 16 + fq * 4) = acc[ni][mi];
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int mb = m0 + wm * 64, nb = n0 + wn * 64;
+  bool vt_tile = false;
+  if (EPI == EPI_QKV) vt_tile = (nb / (p.N / 3)) == 2;         // wave-uniform: head blocks are 64 wide
+  if (!vt_tile) {
+    const int col = (lane & 15) * 4;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 4 + (lane >> 4);
+      const f32x4 v = *(const f32x4*)(tile + row * TLD + col);
+      if (mb + row < p.M) epilogue4<EPI>(p, mb + row, nb + col, v);
+    }
+  } else {
+    // V^T [b][head][d][Tpad]: tokens are the contiguous axis, so lanes run along m (one 2-byte element each, 128 B per store)
+    const int m = mb + lane;
+    if (m < p.M) {
+      const int Dm = p.N / 3;
+      const int f0 = nb - 2 * Dm;
+      const int head = f0 >> 6;
+      const int b = m / p.T, t = m - b * p.T;
+      const int tp = (t & ~15) | (t & 3) | ((t & 4) << 1) | ((t & 8) >> 1);
+      const size_t o0 = ((size_t)(b * p.heads + head) * 64) * p.Tpad + tp;
+      for (int d = 0; d < 64; ++d) {
+        float x = tile[lane * TLD + d];
+        if (p.bias) x += p.bias[nb + d];
+        half_t hh, ll; split_f16(x, hh, ll);
+        p.Vhi[o0 + (size_t)d * p.Tpad] = hh;
+        if (p.Vlo) p.Vlo[o0 + (size_t)d * p.Tpad] = ll;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Tail rows: M = B*T is 4097 for the reference canvas (64x64 patches + cls), one row past a multiple of
 // the tile height. Running that row as a 33rd row of tiles costs a full extra round of workgroups on the
 // 256 CUs, so up to 8 leftover rows are computed by this wave-per-4-columns dot-product kernel instead

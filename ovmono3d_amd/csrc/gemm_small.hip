@@ -35,11 +35,11 @@ template <int NPASS>
 __device__ __forceinline__ void cvt8(const float4 a, const float4 b, half8& h, half8& l) {
   half_t h0, h1, h2, h3, h4, h5, h6, h7, l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0, l6 = 0, l7 = 0;
   if (NPASS == 3) {
-    split_f16(a.x, h0, l0); split_f16(a.y, h1, l1); split_f16(a.z, h2, l2); split_f16(a.w, h3, l3);
-    split_f16(b.x, h4, l4); split_f16(b.y, h5, l5); split_f16(b.z, h6, l6); split_f16(b.w, h7, l7);
+    split_f16_nt(a.x, h0, l0); split_f16_nt(a.y, h1, l1); split_f16_nt(a.z, h2, l2); split_f16_nt(a.w, h3, l3);
+    split_f16_nt(b.x, h4, l4); split_f16_nt(b.y, h5, l5); split_f16_nt(b.z, h6, l6); split_f16_nt(b.w, h7, l7);
   } else {
-    h0 = cvt_f16_rn(a.x); h1 = cvt_f16_rn(a.y); h2 = cvt_f16_rn(a.z); h3 = cvt_f16_rn(a.w);
-    h4 = cvt_f16_rn(b.x); h5 = cvt_f16_rn(b.y); h6 = cvt_f16_rn(b.z); h7 = cvt_f16_rn(b.w);
+    h0 = cvt_f16_rn_nt(a.x); h1 = cvt_f16_rn_nt(a.y); h2 = cvt_f16_rn_nt(a.z); h3 = cvt_f16_rn_nt(a.w);
+    h4 = cvt_f16_rn_nt(b.x); h5 = cvt_f16_rn_nt(b.y); h6 = cvt_f16_rn_nt(b.z); h7 = cvt_f16_rn_nt(b.w);
   }
   h = (half8){h0, h1, h2, h3, h4, h5, h6, h7};
   l = (half8){l0, l1, l2, l3, l4, l5, l6, l7};
@@ -68,33 +68,31 @@ __global__ __launch_bounds__(256) void gemm_f32a_kernel(const SmallGemmParams p)
   const float* ap = p.A + (size_t)am * p.lda + q * 16;
   const half_t* whp = p.Whi + (size_t)(n0 + row) * p.Kpad + q * 16;
   const half_t* wlp = p.Wlo + (size_t)(n0 + row) * p.Kpad + q * 16;
-  float4 ra0, ra1, ra2, ra3; uint4 rwh0, rwh1, rwl0, rwl1;
+  struct Stage { float4 a0, a1, a2, a3; uint4 wh0, wh1, wl0, wl1; };
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#define OVM_GLOAD(k0)                                                                      \
-  do {                                                                                     \
-    const int kq_ = (k0) + q * 16;                                                         \
-    ra0 = (kq_ < p.K) ? *(const float4*)(ap + (k0)) : z4;                                  \
-    ra1 = (kq_ + 4 < p.K) ? *(const float4*)(ap + (k0) + 4) : z4;                          \
-    ra2 = (kq_ + 8 < p.K) ? *(const float4*)(ap + (k0) + 8) : z4;                          \
-    ra3 = (kq_ + 12 < p.K) ? *(const float4*)(ap + (k0) + 12) : z4;                        \
-    rwh0 = *(const uint4*)(whp + (k0)); rwh1 = *(const uint4*)(whp + (k0) + 8);            \
-    if (NPASS == 3) { rwl0 = *(const uint4*)(wlp + (k0)); rwl1 = *(const uint4*)(wlp + (k0) + 8); } \
-  } while (0)
+  auto gload = [&](Stage& r, int k0) {
+    const int kq = k0 + q * 16;
+    r.a0 = (kq < p.K) ? *(const float4*)(ap + k0) : z4;
+    r.a1 = (kq + 4 < p.K) ? *(const float4*)(ap + k0 + 4) : z4;
+    r.a2 = (kq + 8 < p.K) ? *(const float4*)(ap + k0 + 8) : z4;
+    r.a3 = (kq + 12 < p.K) ? *(const float4*)(ap + k0 + 12) : z4;
+    r.wh0 = *(const uint4*)(whp + k0); r.wh1 = *(const uint4*)(whp + k0 + 8);
+    if (NPASS == 3) { r.wl0 = *(const uint4*)(wlp + k0); r.wl1 = *(const uint4*)(wlp + k0 + 8); }
+  };
   const int woff0 = row * 128 + swz_slot<64>(row, 2 * q) * 16;
   const int woff1 = row * 128 + swz_slot<64>(row, 2 * q + 1) * 16;
-#define OVM_LWRITE(buf)                                                                    \
-  do {                                                                                     \
-    char* base_ = smem + (buf) * PARTS * PART;                                             \
-    half8 h_, l_;                                                                          \
-    cvt8<NPASS>(ra0, ra1, h_, l_);                                                         \
-    *(half8*)(base_ + P_AH + woff0) = h_;                                                  \
-    if (NPASS == 3) *(half8*)(base_ + P_AL + woff0) = l_;                                  \
-    cvt8<NPASS>(ra2, ra3, h_, l_);                                                         \
-    *(half8*)(base_ + P_AH + woff1) = h_;                                                  \
-    if (NPASS == 3) *(half8*)(base_ + P_AL + woff1) = l_;                                  \
-    *(uint4*)(base_ + P_WH + woff0) = rwh0; *(uint4*)(base_ + P_WH + woff1) = rwh1;        \
-    if (NPASS == 3) { *(uint4*)(base_ + P_WL + woff0) = rwl0; *(uint4*)(base_ + P_WL + woff1) = rwl1; } \
-  } while (0)
+  auto lwrite = [&](const Stage& r, int buf) {
+    char* base = smem + buf * PARTS * PART;
+    half8 h, l;
+    cvt8<NPASS>(r.a0, r.a1, h, l);
+    *(half8*)(base + P_AH + woff0) = h;
+    if (NPASS == 3) *(half8*)(base + P_AL + woff0) = l;
+    cvt8<NPASS>(r.a2, r.a3, h, l);
+    *(half8*)(base + P_AH + woff1) = h;
+    if (NPASS == 3) *(half8*)(base + P_AL + woff1) = l;
+    *(uint4*)(base + P_WH + woff0) = r.wh0; *(uint4*)(base + P_WH + woff1) = r.wh1;
+    if (NPASS == 3) { *(uint4*)(base + P_WL + woff0) = r.wl0; *(uint4*)(base + P_WL + woff1) = r.wl1; }
+  };
 
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fq = lane >> 4;
@@ -131,22 +129,39 @@ __global__ __launch_bounds__(256) void gemm_f32a_kernel(const SmallGemmParams p)
     }
   };
 
-  if (nk > 0) {
-    OVM_GLOAD(kbeg);
-    OVM_LWRITE(0);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      const bool more = kt + 1 < nk;
-      if (more) OVM_GLOAD(kbeg + (kt + 1) * 64);
-      compute(smem + cur * PARTS * PART);
-      if (NSTAGE == 2) {
-        if (more) OVM_LWRITE(cur ^ 1);
+  if (NSTAGE == 2) {
+    // double-buffered LDS, one k-step of loads in flight
+    if (nk > 0) {
+      Stage r;
+      gload(r, kbeg);
+      lwrite(r, 0);
+      __syncthreads();
+      int cur = 0;
+      for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload(r, kbeg + (kt + 1) * 64);
+        compute(smem + cur * PARTS * PART);
+        if (more) lwrite(r, cur ^ 1);
         __syncthreads();
         cur ^= 1;
-      } else if (more) {
-        __syncthreads();                       // every wave is done reading the single buffer
-        OVM_LWRITE(0);
+      }
+    }
+  } else {
+    // single LDS buffer (32 KB: several workgroups per CU), two register sets = two k-steps of loads in flight
+    Stage r0, r1;
+    if (nk > 0) gload(r0, kbeg);
+    if (nk > 1) gload(r1, kbeg + 64);
+    for (int kt = 0; kt < nk; kt += 2) {
+      lwrite(r0, 0);
+      __syncthreads();
+      if (kt + 2 < nk) gload(r0, kbeg + (kt + 2) * 64);
+      compute(smem);
+      __syncthreads();
+      if (kt + 1 < nk) {
+        lwrite(r1, 0);
+        __syncthreads();
+        if (kt + 3 < nk) gload(r1, kbeg + (kt + 3) * 64);
+        compute(smem);
         __syncthreads();
       }
     }
@@ -232,9 +247,9 @@ int launch_gemm_small(const float* A, int lda, int M, int K, const half_t* Whi, 
   const int tiles = p.tiles_m * p.tiles_n;
   const int nk = Kpad / 64;
   int ksplit = 1;
-  if (tiles < g_target_blocks && nk >= 4) {
+  if (tiles < g_target_blocks && nk >= 8) {
     ksplit = (g_target_blocks + tiles - 1) / tiles;
-    if (ksplit > nk / 2) ksplit = nk / 2;                 // at least two k-steps per workgroup
+    if (ksplit > nk / 4) ksplit = nk / 4;                 // at least four k-steps per workgroup: a split costs a reduce launch
     if (ksplit > g_max_ksplit) ksplit = g_max_ksplit;
     if (ksplit < 1) ksplit = 1;
   }

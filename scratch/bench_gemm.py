@@ -10,7 +10,7 @@ for (N,K) in ((3072,1024),(1024,1024),(4096,1024),(1024,4096)):
     A=torch.randn(M,K,device=dev); W=torch.randn(N,K,device=dev)/math.sqrt(K)
     ah,al=split(A); wh,wl=split(W); Cc=torch.empty(M,N,device=dev)
     for prec in (1,3):
-        for bm,st in ((128,2),(128,3),(256,2),(256,3)):
+        for bm,st in ((128,2),(128,5),(128,6)):
             L.ovm_tune_set(b"gemm_bm", bm); L.ovm_tune_set(b"gemm_stages", st)
             for _ in range(3): L.ovm_op_gemm(ah.data_ptr(),al.data_ptr(),K,wh.data_ptr(),wl.data_ptr(),M,N,K,None,0,Cc.data_ptr(),N,prec,None)
             torch.cuda.synchronize()
@@ -20,7 +20,11 @@ for (N,K) in ((3072,1024),(1024,1024),(4096,1024),(1024,4096)):
             e1.record(); torch.cuda.synchronize()
             ms=e0.elapsed_time(e1)/20
             fl=2.0*M*N*K
-            print(f"N={N} K={K} prec={prec} bm={bm} st={st}: {ms*1e3:.1f} us  alg {fl/ms/1e9:.0f} TF  exec {fl*prec/ms/1e9:.0f} TF")
+            if (N,K)==(3072,1024) or (N,K)==(1024,4096):
+                ref=(A.double()@W.double().T).float()
+                err=((Cc-ref).abs().max()/ref.abs().max()).item()
+            else: err=float('nan')
+            print(f"N={N} K={K} prec={prec} bm={bm} st={st}: {ms*1e3:.1f} us  alg {fl/ms/1e9:.0f} TF  exec {fl*prec/ms/1e9:.0f} TF  err {err:.2e}")
     if (N,K)==(3072,1024):
         ref=(A.double()@W.double().T).float()
         print("check", ((Cc-ref).abs().max()/ref.abs().max()).item())
