@@ -179,7 +179,13 @@ class NativeGroundingDino:
         if entry is None and self.use_graphs:
             self._seen[key] = self._seen.get(key, 0) + 1
             if self._seen[key] >= 2:                                       # first sight ran eagerly: scratch buffers are sized
-                entry = self._capture(key, im, ids_t)
+                try:
+                    entry = self._capture(key, im, ids_t)
+                except RuntimeError as e:                                  # capture refused (driver / allocator state): stay eager, same results
+                    import warnings
+                    warnings.warn(f"HIP graph capture of the GroundingDINO forward failed ({e}); continuing without graphs")
+                    self.use_graphs = False
+                    torch.cuda.synchronize(self.ops.dev)
         if entry is None:
             logits, boxes = self._run(im, ids_t)
         else:
