@@ -179,8 +179,21 @@ def main():
     avg_ms = tot_ms / max(launches, 1)
     flops_launch = kf[dominant] * B
     achieved = flops_launch / (avg_ms * 1e-3) / 1e12
+    # HBM-side bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass over this same command
+    # (profiles/r01/pmc_traffic_*.json documents the command and the gfx950 FETCH_SIZE correction); null if none matches
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_f16x3_vitl14_T4097_b1.json")))
+        wl = tj["workload"]
+        if (wl["model"], wl["canvas"], wl["precision"], wl["batch"]) == (args.model, args.canvas, args.precision, B):
+            key = {"attn": "attn_kernel"}.get(dominant)
+            for kn, kv in tj["kernels"].items():
+                if key and key in kn:
+                    traffic = kv["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        traffic = None
     roofline = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                 "avg_launch_ms": round(avg_ms, 4), "launches": launches,
                 "algorithmic_flops_per_launch": flops_launch,
                 "mfma_passes_per_product": 3 if args.precision == "f16x3" else 1}

@@ -228,6 +228,14 @@ int ovm_tune_set(const char* key, int32_t value);
  * names: "tokens" [B*T][D] fp32, "p2" / "p3" / "p4". Returns the element count or a negative error. */
 int64_t ovm_debug_copy(OvmHandle* h, const char* name, float* dst, int64_t capacity, ovm_stream_t stream);
 
+/* ---- evaluation ("next" row 1 of SURVEY.md 8f) ---------------------------------------------------------------------------
+ * Exact IoU of oriented 3D boxes, iou[i*M + j] for detection i and ground truth j; boxes are 8 corners x 3 floats in
+ * pytorch3d's corner order. Replaces `box3d_overlap` -> pytorch3d `_C.iou_box3d` (cubercnn/evaluation/omni3d_evaluation.py:109-169)
+ * including the screening of the detections: rows of non-coplanar (:68-87) or zero-area (:90-107) detections are 0.
+ * `vol` (optional) receives the intersection volumes. */
+int ovm_box3d_iou(const float* boxes_dt, const float* boxes_gt, int32_t N, int32_t M, float eps_coplanar, float eps_nonzero, float* iou,
+                  float* vol, ovm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,24 +18,10 @@ namespace ovm {
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
+constexpr float kPShift = 14.0f;       // log2 of the scale the main kernel carries its probabilities at
+
 template <int NPASS>
 __device__ __forceinline__ void attn_tail_body(const AttnParams& p, int tb, char* smem);
-
-// 8 fp32 -> fp16 conversions (round-to-nearest, subnormal results kept) in one asm statement: one hazard
-// pad for the lot (see cvt_f16_rn in common.hpp for why these are not left to the compiler).
-__device__ __forceinline__ half8 cvt8_f16_rn(const float* x) {
-  uint32_t r0, r1, r2, r3, r4, r5, r6, r7;
-  asm volatile("s_nop 1\n\tv_cvt_f16_f32 %0, %8\n\tv_cvt_f16_f32 %1, %9\n\tv_cvt_f16_f32 %2, %10\n\tv_cvt_f16_f32 %3, %11\n\t"
-               "v_cvt_f16_f32 %4, %12\n\tv_cvt_f16_f32 %5, %13\n\tv_cvt_f16_f32 %6, %14\n\tv_cvt_f16_f32 %7, %15"
-               : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
-               : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
-  half8 h;
-  h[0] = __builtin_bit_cast(half_t, (uint16_t)r0); h[1] = __builtin_bit_cast(half_t, (uint16_t)r1);
-  h[2] = __builtin_bit_cast(half_t, (uint16_t)r2); h[3] = __builtin_bit_cast(half_t, (uint16_t)r3);
-  h[4] = __builtin_bit_cast(half_t, (uint16_t)r4); h[5] = __builtin_bit_cast(half_t, (uint16_t)r5);
-  h[6] = __builtin_bit_cast(half_t, (uint16_t)r6); h[7] = __builtin_bit_cast(half_t, (uint16_t)r7);
-  return h;
-}
 
 // Software-pipelined over key tiles inside each wave: iteration t issues the S^T MFMAs of tile t+1, the
 // softmax VALU work of tile t and the PV MFMAs of tile t as one basic block, so matrix and vector pipes
@@ -170,16 +156,19 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
         float pv[8], pd[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          pv[e] = __builtin_amdgcn_exp2f(sc[i][8 * sp + e] - m_new);
+          pv[e] = __builtin_amdgcn_exp2f(sc[i][8 * sp + e] - m_new + kPShift);
           psum += pv[e];
         }
-        // hi may come from the packed convert: if it flushes a subnormal to zero the lo part below carries it
+        // Probabilities are carried scaled by 2^kPShift (<= 16384, no fp16 overflow; the scale cancels in O / l). That moves
+        // the fp16 subnormal range down to 3.7e-9 of the row maximum, so both parts can use the compiler's packed converts
+        // (v_cvt_pk_f16_f32 flushes subnormal results): what a flush can drop is bounded by 4097 keys x 3.7e-9 (hi) and
+        // 4097 x 7.6e-6 x 2^-11 (lo) of the largest term - 1.5e-5 each in the worst case. No asm block in the loop any more,
+        // so the scheduler is free to interleave this VALU work with the MFMAs of the neighbouring tiles.
 #pragma unroll
         for (int e = 0; e < 8; ++e) ph[i][sp][e] = (half_t)pv[e];
         if (NPASS == 3) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) pd[e] = pv[e] - (float)ph[i][sp][e];
-          pl[i][sp] = cvt8_f16_rn(pd);
+          for (int e = 0; e < 8; ++e) { pd[e] = pv[e] - (float)ph[i][sp][e]; pl[i][sp][e] = (half_t)pd[e]; }
         }
       }
     l_run = l_run * alpha + psum;

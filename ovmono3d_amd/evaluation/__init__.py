@@ -1,1 +1,2 @@
 from .omni3d_evaluation import Omni3DEvaluator, inference_on_dataset, instances_to_coco_json  # noqa: F401
+from .omni3d_eval import Omni3Deval, Omni3DParams, box3d_overlap, evaluate_omni3d, omni3d_json_to_gt  # noqa: F401

@@ -3,8 +3,7 @@
 Mirrors reference cubercnn/evaluation/omni3d_evaluation.py:626-734 (``inference_on_dataset``: warm-up reset
 after 5 iterations, data / compute / eval timers, ``torch.cuda.synchronize()`` before stopping the compute
 timer, depth stacking :661-665, gather to rank 0 :717-720) and :1200-1252 (``instances_to_coco_json``).
-The AP evaluators (Omni3DEvaluationHelper.evaluate, :271-427, 1394-2340) are the "next" row of the scope
-table and are not part of this build.
+The AP computation (Omni3Deval with true 3D IoU) lives in ``omni3d_eval.py``.
 """
 from __future__ import annotations
 

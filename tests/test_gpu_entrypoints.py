@@ -82,7 +82,12 @@ def test_eval_only_entry_point(device, tmp_path):
     names = _write_images(str(root / "imgs"), 3)
     images = [{"id": 100 + i, "file_path": f"imgs/{n}.png", "width": 160, "height": 120 + 20 * i, "dataset_id": 0,
                "K": [[300.0, 0, 80], [0, 300.0, 60 + 10 * i], [0, 0, 1]]} for i, n in enumerate(names)]
-    (root / "Omni3D" / "Objectron_test.json").write_text(json.dumps({"images": images, "annotations": [], "categories": []}))
+    c3 = [[x, y, z] for z in (4.5, 5.5) for (x, y) in ((-0.5, -0.5), (0.5, -0.5), (0.5, 0.5), (-0.5, 0.5))]
+    anns = [{"id": 1, "image_id": 100, "category_id": 3, "bbox2D_proj": [20, 20, 80, 70], "bbox3D_cam": c3, "center_cam": [0, 0, 5.0],
+             "behind_camera": False},
+            {"id": 2, "image_id": 101, "category_id": 7, "bbox2D_proj": [-1, -1, -1, -1], "bbox2D_tight": [30, 30, 90, 90], "bbox3D_cam": c3,
+             "center_cam": [0, 0, 5.0], "behind_camera": True}]
+    (root / "Omni3D" / "Objectron_test.json").write_text(json.dumps({"images": images, "annotations": anns, "categories": []}))
     out = tmp_path / "out"
     cmd = [sys.executable, os.path.join(ROOT, "tools", "train_net.py"), "--eval-only", "--config-file",
            os.path.join(ROOT, "configs", "OVMono3D_dinov2_SFP.yaml"), "--datasets-root", str(root / "Omni3D"), "--image-root", str(root),
@@ -92,4 +97,6 @@ def test_eval_only_entry_point(device, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.loads((out / "inference" / "iter_final" / "Objectron_test" / "omni_instances_results.json").read_text())
     assert len(res) > 0 and {"image_id", "category_id", "bbox", "score", "bbox3D", "pose", "depth"} <= set(res[0])
+    ap = json.loads((out / "inference" / "iter_final" / "Objectron_test" / "omni_ap.json").read_text())      # AP evaluator ran on the ground truth
+    assert {"AP", "AP15", "AP25", "AP50", "APn", "APm", "APf"} <= set(ap["bbox_3D"]) and {"AP", "AP50", "AP75"} <= set(ap["bbox_2D"])
     assert {r_["image_id"] for r_ in res} <= {100, 101, 102}

@@ -26,7 +26,7 @@ from ovmono3d_amd.checkpoint import DetectionCheckpointer  # noqa: E402
 from ovmono3d_amd.data import (DatasetMapper3D, build_detection_test_loader, load_omni3d_json,  # noqa: E402
                                merge_oracle2d_to_detection_dicts)
 from ovmono3d_amd.defaults import make_cfg  # noqa: E402
-from ovmono3d_amd.evaluation import Omni3DEvaluator, inference_on_dataset  # noqa: E402
+from ovmono3d_amd.evaluation import Omni3DEvaluator, evaluate_omni3d, inference_on_dataset, omni3d_json_to_gt  # noqa: E402
 from ovmono3d_amd.evaluation.distributed import get_rank, get_world_size  # noqa: E402
 from ovmono3d_amd.modeling import build_model  # noqa: E402
 
@@ -55,6 +55,15 @@ def do_test(cfg, model, mode="base", datasets_root="datasets/Omni3D", image_root
             with open(os.path.join(out_dir, name, "omni_instances_results.json"), "w") as f:
                 json.dump([inst for r in results for inst in r["instances"]], f)
             logger.info("%s: %d images, %d detections", name, len(results), sum(len(r["instances"]) for r in results))
+            # AP2D / AP3D (true 3D IoU on the device) when the annotation file carries ground truth
+            with open(os.path.join(datasets_root, name + ".json")) as f:
+                gts = omni3d_json_to_gt(json.load(f))
+            if gts:
+                ap = evaluate_omni3d(gts, [inst for r in results for inst in r["instances"]])
+                with open(os.path.join(out_dir, name, "omni_ap.json"), "w") as f:
+                    json.dump(ap, f)
+                logger.info("%s: AP2D %.2f  AP3D %.2f  (AP3D@15 %.2f, @25 %.2f, @50 %.2f)", name, ap["bbox_2D"]["AP"], ap["bbox_3D"]["AP"],
+                            ap["bbox_3D"]["AP15"], ap["bbox_3D"]["AP25"], ap["bbox_3D"]["AP50"])
 
 
 def main(args):
