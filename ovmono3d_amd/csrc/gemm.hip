@@ -78,13 +78,14 @@ template <int EPI, int AMODE>
 static int launch_prec(const GemmParams& p, int npass, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return OVM_OK;
   const int bm = pick_bm(p);
-  // Default: up to three rounds of tiles (<= 768 on 256 CUs) run on the wave-specialised kernel (one workgroup per CU, no DMA
-  // issue or global-memory waits in the MFMA waves: +7..+16 % at the ViT-L qkv / proj / fc2 shapes); larger grids keep the
-  // symmetric two-workgroups-per-CU kernel, whose co-resident workgroup hides the per-tile prologue and epilogue (fc1).
+  // Default: up to two rounds of tiles (<= 512 on 256 CUs) run on the wave-specialised kernel (one workgroup per CU, no DMA
+  // issue or global-memory waits in the MFMA waves: +11..+16 % at the ViT-L proj / fc2 shapes); larger grids keep the symmetric
+  // two-workgroups-per-CU kernel, whose co-resident workgroup hides the per-tile prologue and epilogue (qkv with its V^T
+  // scatter: 102 vs 110 us, fc1: 122 vs 135 us in favour of the symmetric kernel).
   const int tail_rows = p.M % 128;                    // <= 8 leftover rows ride along as dot-product workgroups, not as a row of tiles
   const long tiles_m = (g_tail_rows && tail_rows > 0 && tail_rows <= 8 && p.M > 128 && p.K % 64 == 0) ? p.M / 128 : (p.M + 127) / 128;
   const long tiles = tiles_m * ((p.N + 127) / 128);
-  const int st = g_force_stages ? g_force_stages : (tiles <= 768 ? 6 : 2);
+  const int st = g_force_stages ? g_force_stages : (tiles <= 512 ? 6 : 2);
   if (st == 5) return npass == 3 ? launch_ws<3, 32, 4, EPI, AMODE>(p, s) : launch_ws<1, 64, 4, EPI, AMODE>(p, s);
   if (st == 6) return npass == 3 ? launch_ws<3, 32, 3, EPI, AMODE>(p, s) : launch_ws<1, 64, 3, EPI, AMODE>(p, s);
   if (npass == 3) {
