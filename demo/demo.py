@@ -41,6 +41,10 @@ def do_test(args, cfg, model):
     thres = args.threshold
     os.makedirs(cfg.OUTPUT_DIR, exist_ok=True)
     resize = ResizeShortestEdge(cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
+    gpu_resize = None
+    if bool(cfg.MODEL.AMD.get("GPU_RESIZE", False)):
+        from ovmono3d_amd.data.gpu_resize import ResizeShortestEdgeGPU
+        gpu_resize = ResizeShortestEdgeGPU(cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
     use_gdino_head = cfg.MODEL.ROI_HEADS.NAME == "ROIHeads3DGDINO"
     for name in ims:
         im_name = os.path.splitext(name)[0]
@@ -53,8 +57,11 @@ def do_test(args, cfg, model):
             focal_length = 4.0 * h / 2                                       # demo.py:63-65
         px, py = (w / 2, h / 2) if len(principal_point) == 0 else principal_point
         K = np.array([[focal_length, 0.0, px], [0.0, focal_length, py], [0.0, 0.0, 1.0]])
-        image = resize(im)
-        d = {"image": torch.as_tensor(np.ascontiguousarray(image.transpose(2, 0, 1))), "height": h, "width": w, "K": K}
+        if gpu_resize is not None:                                           # device-side ResizeShortestEdge, bit-identical to Pillow's
+            image_t = gpu_resize(torch.from_numpy(np.ascontiguousarray(im)).cuda()).permute(2, 0, 1)
+        else:
+            image_t = torch.as_tensor(np.ascontiguousarray(resize(im).transpose(2, 0, 1)))
+        d = {"image": image_t, "height": h, "width": w, "K": K}
         if boxes_per_img is not None:
             inst = boxes_per_img.get(im_name, [])
             d["oracle2D"] = {"gt_bbox2D": torch.tensor([[b["bbox"][0], b["bbox"][1], b["bbox"][0] + b["bbox"][2],

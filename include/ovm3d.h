@@ -236,6 +236,16 @@ int64_t ovm_debug_copy(OvmHandle* h, const char* name, float* dst, int64_t capac
 int ovm_box3d_iou(const float* boxes_dt, const float* boxes_gt, int32_t N, int32_t M, float eps_coplanar, float eps_nonzero, float* iou,
                   float* vol, ovm_stream_t stream);
 
+/* ---- data feeding ("next" row 2 of SURVEY.md 8f) ---------------------------------------------------------------------------
+ * uint8 bilinear resize bit-identical to Pillow's Image.resize(size, BILINEAR), i.e. to detectron2's ResizeShortestEdge on
+ * uint8 images (reference demo/demo.py:79-83, cubercnn/data/dataset_mapper.py:62-72). ovm_host_pil_bilinear_coeffs builds one
+ * axis' window bounds and 22-bit integer weights on the host (call with null tables to get ksize); ovm_resize_bilinear_u8 runs
+ * the horizontal then the vertical pass on the device. src strides are in elements over [H][W][C]. */
+int ovm_host_pil_bilinear_coeffs(int32_t in_size, int32_t out_size, int32_t* bounds, int32_t* coefs, int32_t coefs_capacity);
+int ovm_resize_bilinear_u8(const uint8_t* src, int32_t H, int32_t W, int32_t C, int64_t sy, int64_t sx, int64_t sc, int32_t outH, int32_t outW,
+                           const int32_t* xbounds, const int32_t* xcoefs, int32_t xksize, const int32_t* ybounds, const int32_t* ycoefs,
+                           int32_t yksize, uint8_t* tmp, uint8_t* dst, ovm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

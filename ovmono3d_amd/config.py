@@ -262,5 +262,7 @@ def get_cfg_defaults(cfg: CfgNode) -> CfgNode:
                                  # GroundingDINO branch of ROIHeads3DGDINO: checkpoint (the reference hard-codes this path,
                                  # roi_heads_gdino.py:87-91; "synthetic://gdino?seed=N" = random init) and bert-base-uncased vocab.txt
                                  GDINO_WEIGHTS="./checkpoints/groundingdino_swinb_cogcoor.pth", BERT_VOCAB="",
-                                 GDINO_OVERLAP=True, GDINO_GRAPHS=True))
+                                 GDINO_OVERLAP=True, GDINO_GRAPHS=True,
+                                 # ResizeShortestEdge on the device (bit-identical to the host's Pillow resize)
+                                 GPU_RESIZE=True))
     return cfg

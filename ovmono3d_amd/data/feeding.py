@@ -92,6 +92,11 @@ class DatasetMapper3D:
         self.resize = ResizeShortestEdge(cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
         self.use_depth = bool(cfg.MODEL.DINO.USE_DEPTH_FUSION) and depth_dir is not None
         self.depth_dir = depth_dir
+        # device-side ResizeShortestEdge (bit-identical to the Pillow path; gpu_resize.py) when a HIP device is present
+        self.gpu_resize = None
+        if bool(cfg.MODEL.AMD.get("GPU_RESIZE", False)) and str(cfg.MODEL.DEVICE).startswith("cuda") and torch.cuda.is_available():
+            from .gpu_resize import ResizeShortestEdgeGPU
+            self.gpu_resize = ResizeShortestEdgeGPU(cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
 
     def __call__(self, d: Dict) -> Dict:
         d = dict(d)
@@ -106,8 +111,11 @@ class DatasetMapper3D:
                                                             mode="bilinear", align_corners=False)[0, 0].numpy()
             except Exception:
                 depth = np.zeros(image.shape[:2], dtype=np.float32)
-        image = self.resize(image)
-        d["image"] = torch.as_tensor(np.ascontiguousarray(image.transpose(2, 0, 1)))
+        if self.gpu_resize is not None:
+            d["image"] = self.gpu_resize(torch.from_numpy(np.ascontiguousarray(image)).cuda()).permute(2, 0, 1)   # CHW view of the HWC result
+        else:
+            image = self.resize(image)
+            d["image"] = torch.as_tensor(np.ascontiguousarray(image.transpose(2, 0, 1)))
         if depth is not None:
             d["depth"] = torch.as_tensor(np.ascontiguousarray(self.resize(depth))).unsqueeze(0)
         return d

@@ -49,7 +49,7 @@ EXPORTS = [
     "ovm_rpn_box_forward", "ovm_gather_records", "ovm_host_interp_pos_embed", "ovm_host_shard_range",
     "ovm_op_split_f16", "ovm_op_gemm", "ovm_op_layernorm", "ovm_op_attention", "ovm_op_roi_align",
     "ovm_op_cube_decode", "ovm_op_nms", "ovm_debug_copy", "ovm_profile_enable", "ovm_profile_read",
-    "ovm_comm_unique_id", "ovm_comm_init", "ovm_comm_destroy", "ovm_tune_set", "ovm_gdino_postprocess", "ovm_box3d_iou",
+    "ovm_comm_unique_id", "ovm_comm_init", "ovm_comm_destroy", "ovm_tune_set", "ovm_gdino_postprocess", "ovm_box3d_iou", "ovm_host_pil_bilinear_coeffs", "ovm_resize_bilinear_u8",
     "ovm_g_pack_weight", "ovm_g_linear", "ovm_g_layernorm", "ovm_g_bmm", "ovm_g_bmm2", "ovm_g_softmax", "ovm_g_softmax2", "ovm_g_eltwise", "ovm_g_gather_rows",
     "ovm_g_groupnorm", "ovm_g_msdeform", "ovm_g_sine_embed", "ovm_g_normalize_image", "ovm_g_topk", "ovm_g_rowmax",
 ]
@@ -95,6 +95,8 @@ def load() -> C.CDLL:
     lib.ovm_comm_init.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     lib.ovm_comm_destroy.argtypes = [vp]
     lib.ovm_tune_set.argtypes = [C.c_char_p, i32]
+    lib.ovm_host_pil_bilinear_coeffs.argtypes = [i32, i32, vp, vp, i32]
+    lib.ovm_resize_bilinear_u8.argtypes = [vp, i32, i32, i32, i64, i64, i64, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.ovm_box3d_iou.argtypes = [vp, vp, i32, i32, f32, f32, vp, vp, vp]
     lib.ovm_g_pack_weight.argtypes = [vp, i32, i32, i32, vp, vp, vp]
     lib.ovm_g_linear.argtypes = [vp, i32, i32, i32, vp, vp, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp]
