@@ -6,6 +6,7 @@ import subprocess
 import sys
 
 import numpy as np
+import torch
 import pytest
 
 from common import ROOT
@@ -13,12 +14,12 @@ from common import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _write_images(folder, n=2):
+def _write_images(folder, n=2, size=None):
     from PIL import Image
     rng = np.random.default_rng(0)
     names = []
     for i in range(n):
-        arr = rng.integers(0, 255, (120 + 20 * i, 160, 3), dtype=np.uint8)
+        arr = rng.integers(0, 255, ((120 + 20 * i, 160, 3) if size is None else (size[0], size[1], 3)), dtype=np.uint8)
         name = f"img{i:03d}"
         Image.fromarray(arr).save(os.path.join(folder, name + ".png"))
         names.append(name)
@@ -100,3 +101,29 @@ def test_eval_only_entry_point(device, tmp_path):
     ap = json.loads((out / "inference" / "iter_final" / "Objectron_test" / "omni_ap.json").read_text())      # AP evaluator ran on the ground truth
     assert {"AP", "AP15", "AP25", "AP50", "APn", "APm", "APf"} <= set(ap["bbox_3D"]) and {"AP", "AP50", "AP75"} <= set(ap["bbox_2D"])
     assert {r_["image_id"] for r_ in res} <= {100, 101, 102}
+
+
+def test_oracle2d_producer_roundtrip(device, tmp_path):
+    """tools/make_oracle2d.py writes the file format merge_oracle2d_to_detection_dicts reads (reference build.py:45-54)."""
+    from ovmono3d_amd.data.feeding import load_omni3d_json, merge_oracle2d_to_detection_dicts
+    root = tmp_path / "datasets"; (root / "Omni3D").mkdir(parents=True); (root / "imgs").mkdir()
+    names = _write_images(str(root / "imgs"), 2, size=(300, 400))
+    images = [{"id": 7 + i, "file_path": f"imgs/{n}.png", "width": 400, "height": 300, "dataset_id": 0, "K": [[500.0, 0, 200], [0, 500.0, 150], [0, 0, 1]]}
+              for i, n in enumerate(names)]
+    cats = [{"id": 3, "name": "chair"}, {"id": 9, "name": "dining table"}]
+    ds = root / "Omni3D" / "Toy_test.json"
+    ds.write_text(json.dumps({"images": images, "annotations": [], "categories": cats}))
+    out = root / "Omni3D" / "gdino_toy_oracle_2d.json"
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "make_oracle2d.py"), "--config-file", os.path.join(ROOT, "configs", "OVMono3D_dinov2_SFP.yaml"),
+           "--dataset", str(ds), "--image-root", str(root), "--output", str(out), "INPUT.MIN_SIZE_TEST", "300", "INPUT.MAX_SIZE_TEST", "400",
+           "MODEL.AMD.GDINO_WEIGHTS", "synthetic://gdino?seed=1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    data = json.loads(out.read_text())
+    assert [d["image_id"] for d in data] == [7, 8] and all(i["category_id"] in (3, 9) for d in data for i in d["instances"])
+    assert sum(len(d["instances"]) for d in data) > 0
+    dicts = load_omni3d_json(str(ds), str(root))
+    merge_oracle2d_to_detection_dicts(dicts, str(out))
+    o = dicts[0]["oracle2D"]
+    assert o["gt_bbox2D"].shape[1] == 4 and len(o["gt_classes"]) == len(o["gt_scores"]) == o["gt_bbox2D"].shape[0]
+    assert torch.isfinite(o["gt_bbox2D"]).all()              # not clipped to the image: the reference's GroundingDINO glue does not clip either
