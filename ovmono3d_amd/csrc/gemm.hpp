@@ -621,5 +621,6 @@ int launch_gemm_small(const float* A, int lda, int M, int K, const half_t* Whi, 
 void gemm_small_set(int target_blocks, int max_ksplit);
 void gemm_small_set_stages(int n);
 void glinear_set_small_max_tiles(int t);
+void gbmm_set_tiled(int v);
 
 }  // namespace ovm

@@ -17,6 +17,7 @@ namespace {
 struct Scratch { void* p = nullptr; size_t cap = 0; };
 Scratch g_s[2];
 long g_small_max_tiles = -1;      // -1: built-in heuristic
+int g_bmm_tiled = 1;
 void* scratch(int i, size_t bytes) {
   if (g_s[i].cap < bytes) {
     if (g_s[i].p) { (void)hipDeviceSynchronize(); (void)hipFree(g_s[i].p); }
@@ -95,6 +96,68 @@ __global__ __launch_bounds__(256) void bmm_kernel(const float* __restrict__ A, c
   }
 }
 
+
+// Register-blocked variant for M >= 48: a workgroup computes a (16*TM) x (16*TN) tile, each thread TM x TN outputs (rows
+// ty + 16 i, columns tx + 16 j: stores coalesced along tx), k-steps of 16 through LDS. Same fp32 FMA order per output as
+// bmm_kernel (k ascending), so the two produce identical results.
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void bmm_tile_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ Cm, int M,
+                                                       int N, int K, int lda, int ldb, int ldc, long sA, long sB, long sC, int nb2, long sA2,
+                                                       long sB2, long sC2, int transB, float alpha) {
+  __shared__ float As[16][16 * TM + 1], Bs[16][16 * TN + 1];
+  const int z1 = blockIdx.z / nb2, z2 = blockIdx.z - z1 * nb2;
+  const float* a = A + (size_t)z1 * sA + (size_t)z2 * sA2; const float* b = Bm + (size_t)z1 * sB + (size_t)z2 * sB2;
+  float* c = Cm + (size_t)z1 * sC + (size_t)z2 * sC2;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m0 = blockIdx.y * 16 * TM, n0 = blockIdx.x * 16 * TN;
+  float acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {                               // A rows (k contiguous): thread (row ty + 16 i, k tx)
+      const int m = m0 + ty + 16 * i;
+      As[tx][ty + 16 * i] = (m < M && k0 + tx < K) ? a[(size_t)m * lda + k0 + tx] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if (transB) {                                              // B is N x K: thread (row ty + 16 j, k tx)
+        const int n = n0 + ty + 16 * j;
+        Bs[tx][ty + 16 * j] = (n < N && k0 + tx < K) ? b[(size_t)n * ldb + k0 + tx] : 0.f;
+      } else {                                                   // B is K x N: thread (k ty, column tx + 16 j)
+        const int n = n0 + tx + 16 * j;
+        Bs[ty][tx + 16 * j] = (k0 + ty < K && n < N) ? b[(size_t)(k0 + ty) * ldb + n] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = As[k][ty + 16 * i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = Bs[k][tx + 16 * j];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + ty + 16 * i;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + tx + 16 * j;
+      if (n < N) c[(size_t)m * ldc + n] = alpha * acc[i][j];
+    }
+  }
+}
+
 // sums the split-K partials of bmm_kernel: part [ksplit][nz][M][N] -> c (batch strides as in bmm_kernel)
 __global__ void bmm_reduce_kernel(const float* __restrict__ part, float* __restrict__ Cm, int ksplit, int nz, int M, int N, int ldc, long sC,
                                   int nb2, long sC2, float alpha) {
@@ -118,6 +181,33 @@ __global__ __launch_bounds__(256) void softmax_kernel(float* __restrict__ x, int
   float* xr = x + (size_t)row * ld;
   const float* br = bias ? bias + (size_t)((row / bias_div) % bias_rows) * bias_ld : nullptr;
   const float* b2 = bias2 ? bias2 + ((size_t)(row / d2) * m2 + (row % m2)) * bias_ld : nullptr;
+  if (cols <= 512) {
+    // short rows (Swin windows of 144 keys, 16 text tokens): keep the row in registers - one read of x and of the biases, one
+    // write; same operation order as the generic path below (bit-identical results)
+    float v[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int j = lane + 64 * t;
+      v[t] = (j < cols) ? xr[j] + (br ? br[j] : 0.f) + (b2 ? b2[j] : 0.f) : -INFINITY;
+      mx = fmaxf(mx, v[t]);
+    }
+    mx = wave_max(mx);
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int j = lane + 64 * t;
+      if (j < cols) { v[t] = expf(v[t] - mx); s += v[t]; }
+    }
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int j = lane + 64 * t;
+      if (j < cols) xr[j] = v[t] * inv;
+    }
+    return;
+  }
   float mx = -INFINITY;
   for (int j = lane; j < cols; j += 64) mx = fmaxf(mx, xr[j] + (br ? br[j] : 0.f) + (b2 ? b2[j] : 0.f));
   mx = wave_max(mx);
@@ -259,7 +349,7 @@ inline dim3 g1(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)
 
 }  // namespace
 
-namespace ovm { void glinear_set_small_max_tiles(int t) { g_small_max_tiles = t; } }
+namespace ovm { void glinear_set_small_max_tiles(int t) { g_small_max_tiles = t; } void gbmm_set_tiled(int v) { g_bmm_tiled = v; } }
 
 extern "C" {
 
@@ -332,6 +422,15 @@ int ovm_g_bmm2(const float* a, const float* b, float* c, int32_t nb1, int32_t nb
   for (long z0 = 0; z0 < nz; z0 += 65535 / nb2 * nb2) {          // grid.z limit; chunks keep z2 aligned
     const long cnt = (nz - z0 < (long)(65535 / nb2 * nb2)) ? nz - z0 : (long)(65535 / nb2 * nb2);
     const long o1 = z0 / nb2;
+    if (M >= 48 && g_bmm_tiled) {                                 // register-blocked tiles: 48 x 16 / 32 / 48
+#define OVM_BMM_TILE(TN_)                                                                                                          \
+      hipLaunchKernelGGL((bmm_tile_kernel<3, TN_>), dim3((N + 16 * TN_ - 1) / (16 * TN_), (M + 47) / 48, (unsigned)cnt), dim3(256), 0,       \
+                         (hipStream_t)stream, a + o1 * sA1, b + o1 * sB1, c + o1 * sC1, M, N, K, lda, ldb, ldc, (long)sA1, (long)sB1, (long)sC1, \
+                         nb2, (long)sA2, (long)sB2, (long)sC2, transB, alpha)
+      if (N <= 16) OVM_BMM_TILE(1); else if (N <= 32) OVM_BMM_TILE(2); else OVM_BMM_TILE(3);
+#undef OVM_BMM_TILE
+      continue;
+    }
     hipLaunchKernelGGL(bmm_kernel, dim3((N + 15) / 16, (M + 15) / 16, (unsigned)cnt), dim3(256), 0, (hipStream_t)stream, a + o1 * sA1,
                        b + o1 * sB1, c + o1 * sC1, M, N, K, lda, ldb, ldc, (long)sA1, (long)sB1, (long)sC1, nb2, (long)sA2, (long)sB2,
                        (long)sC2, transB, alpha, tiles_n, (K + 15) / 16 * 16, (float*)nullptr);

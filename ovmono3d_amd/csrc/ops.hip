@@ -159,6 +159,7 @@ int ovm_tune_set(const char* key, int32_t value) {
   if (!strcmp(key, "attn_tail")) { attn_set_tail_rows(value); return OVM_OK; }
   if (!strcmp(key, "glin_small_max_tiles")) { glinear_set_small_max_tiles(value); return OVM_OK; }
   if (!strcmp(key, "glin_target_blocks")) { gemm_small_set(value, -1); return OVM_OK; }
+  if (!strcmp(key, "gbmm_tiled")) { gbmm_set_tiled(value); return OVM_OK; }
   if (!strcmp(key, "glin_stages")) { gemm_small_set_stages(value); return OVM_OK; }
   if (!strcmp(key, "glin_max_ksplit")) { gemm_small_set(-1, value); return OVM_OK; }
   return OVM_ERR_INVALID;

@@ -30,6 +30,18 @@ def test_generic_ops(device):
     assert_close(o.bmm(a, bb, True, 0.5), 0.5 * (a.cpu() @ bb.cpu().transpose(1, 2)), 2e-6, "bmm^T")
     bn = torch.randn(3, 20, 31, generator=g).to(device)
     assert_close(o.bmm(a, bn, False), a.cpu() @ bn.cpu(), 2e-6, "bmm")
+    # register-blocked route (M >= 48) against the 16 x 16 kernel: same FMA order -> identical bits; ragged M / N / K, both B layouts
+    from ovmono3d_amd import lib as _lib
+    for (Bt, M_, N_, K_) in ((5, 144, 144, 32), (5, 144, 32, 144), (3, 900, 16, 37), (2, 77, 50, 900)):
+        a2 = torch.randn(Bt, M_, K_, generator=g).to(device)
+        for tB in (True, False):
+            b2 = torch.randn(Bt, N_, K_, generator=g).to(device) if tB else torch.randn(Bt, K_, N_, generator=g).to(device)
+            _lib.load().ovm_tune_set(b"gbmm_tiled", 0)
+            base = o.bmm(a2, b2, tB, 0.7)
+            _lib.load().ovm_tune_set(b"gbmm_tiled", 1)
+            assert torch.equal(o.bmm(a2, b2, tB, 0.7), base)
+            ref2 = 0.7 * (a2.cpu().double() @ (b2.cpu().double().transpose(1, 2) if tB else b2.cpu().double()))
+            assert_close(base, ref2.float(), 2e-6, "bmm tiled")
     ak = torch.randn(4, 16, 6015, generator=g).to(device)                 # long reduction on a thin grid -> split-K route
     bk = torch.randn(4, 6015, 40, generator=g).to(device)
     assert_close(o.bmm(ak, bk, False), (ak.cpu().double() @ bk.cpu().double()).float(), 2e-6, "bmm split-K")
