@@ -167,6 +167,10 @@ int ovm_op_split_f16(const float* x, int64_t n, uint16_t* hi, uint16_t* lo, ovm_
 int ovm_op_gemm(const uint16_t* a_hi, const uint16_t* a_lo, int32_t lda, const uint16_t* w_hi, const uint16_t* w_lo,
                 int32_t M, int32_t N, int32_t K, const float* bias, int32_t relu, float* c, int32_t ldc,
                 int32_t precision, ovm_stream_t stream);
+/* hi, lo [rows][K] (K % 32 == 0) -> out [rows][K/32][hi 32 | lo 32]: the interleaved operand image of the split-precision GEMM.
+ * In split mode ovm_op_gemm takes w_hi = such an image and w_lo = w_hi + 32; activations may be plain arrays or an image
+ * (a_lo = a_hi + 32, lda = 2K). */
+int ovm_op_interleave(const uint16_t* hi, const uint16_t* lo, int64_t rows, int32_t K, uint16_t* out, ovm_stream_t stream);
 int ovm_op_layernorm(const float* x, int32_t M, int32_t D, const float* gamma, const float* beta, float eps,
                      float* y, ovm_stream_t stream);
 int ovm_op_attention(const float* qkv, int32_t B, int32_t T, int32_t heads, float* out, int32_t precision,

@@ -139,26 +139,30 @@ int upload_vec(OvmHandle* h, const std::vector<float>& v, float** out) {
   return OVM_OK;
 }
 
-// Pack a host [N][K] fp32 matrix (already in GEMM k-order) into device split fp16 [Npad][Kpad].
+// Pack a host [N][K] fp32 matrix (already in GEMM k-order) into device fp16: one-pass mode [Npad][Kpad]; split mode the
+// interleaved image [Npad][Kpad/32][hi 32 | lo 32] the GEMM kernels stream (gemm.hpp), w.lo = w.hi + 32.
 int upload_packed(OvmHandle* h, const std::vector<float>& w, int N, int K, int Kpad, PackedLinear* out) {
   const int Npad = (N + 127) / 128 * 128;
-  std::vector<half_t> hi((size_t)Npad * Kpad, (half_t)0.f), lo;
-  if (h->npass == 3) lo.assign((size_t)Npad * Kpad, (half_t)0.f);
+  const bool il = h->npass == 3;
+  if (il && Kpad % 32 != 0) { h->err = "packed K must be a multiple of 32"; return OVM_ERR_SHAPE; }
+  const size_t ld = il ? (size_t)2 * Kpad : (size_t)Kpad;
+  std::vector<half_t> buf((size_t)Npad * ld, (half_t)0.f);
   for (int n = 0; n < N; ++n)
     for (int k = 0; k < K; ++k) {
       const float x = w[(size_t)n * K + k];
       const half_t hh = (half_t)x;
-      hi[(size_t)n * Kpad + k] = hh;
-      if (h->npass == 3) lo[(size_t)n * Kpad + k] = (half_t)((x - (float)hh) * kLoScale);
+      if (il) {
+        const size_t o = (size_t)n * ld + (size_t)(k >> 5) * 64 + (k & 31);
+        buf[o] = hh;
+        buf[o + 32] = (half_t)((x - (float)hh) * kLoScale);
+      } else {
+        buf[(size_t)n * ld + k] = hh;
+      }
     }
-  int r = dalloc(h, &out->w.hi, hi.size());
+  int r = dalloc(h, &out->w.hi, buf.size());
   if (r) return r;
-  HCHECK(h, hipMemcpy(out->w.hi, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
-  if (h->npass == 3) {
-    r = dalloc(h, &out->w.lo, lo.size());
-    if (r) return r;
-    HCHECK(h, hipMemcpy(out->w.lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
-  }
+  HCHECK(h, hipMemcpy(out->w.hi, buf.data(), buf.size() * 2, hipMemcpyHostToDevice));
+  out->w.lo = il ? out->w.hi + 32 : nullptr;
   out->N = N; out->K = Kpad;
   return OVM_OK;
 }

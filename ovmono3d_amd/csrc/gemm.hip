@@ -11,12 +11,13 @@ void gemm_set_stages(int n) { g_force_stages = n; }
 void gemm_set_force_bm(int bm) { g_force_bm = bm; }
 void gemm_set_tail_rows(int on) { g_tail_rows = on; }
 
-template <int NPASS, int BK, int BM, int NSTAGE, int EPI, int AMODE>
+template <int NPASS, int BK, int BM, int NSTAGE, int EPI, int AMODE, bool AIL = false>
 static int launch_one(const GemmParams& p, hipStream_t s) {
   constexpr int smem = NSTAGE * (BM + 128) * BK * 2 * ((NPASS == 3) ? 2 : 1);
   if (p.K % BK != 0) return OVM_ERR_SHAPE;
   GemmParams q = p;
   q.M_total = p.M; q.tail_begin = p.M; q.main_tiles = 0;
+  q.ldw = (NPASS == 3) ? 2 * p.K : p.K;
   int tail_blocks = 0;
   const int tail = p.M % 128;
   if (g_tail_rows && tail > 0 && tail <= 8 && p.M > 128 && p.K % 64 == 0) {
@@ -32,20 +33,21 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     if (smem > 65536 &&
-        hipFuncSetAttribute((const void*)gemm_kernel<NPASS, BK, BM, NSTAGE, EPI, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        hipFuncSetAttribute((const void*)gemm_kernel<NPASS, BK, BM, NSTAGE, EPI, AMODE, AIL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return OVM_ERR_HIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<NPASS, BK, BM, NSTAGE, EPI, AMODE>), dim3(q.main_tiles + tail_blocks), dim3(BM * 2), smem, s, q);
+  hipLaunchKernelGGL((gemm_kernel<NPASS, BK, BM, NSTAGE, EPI, AMODE, AIL>), dim3(q.main_tiles + tail_blocks), dim3(BM * 2), smem, s, q);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 
-template <int NPASS, int BK, int NS, int EPI, int AMODE>
+template <int NPASS, int BK, int NS, int EPI, int AMODE, bool AIL = false>
 static int launch_ws(const GemmParams& p, hipStream_t s) {
   constexpr int smem = NS * (128 + 128) * BK * 2 * ((NPASS == 3) ? 2 : 1);
   if (p.K % BK != 0) return OVM_ERR_SHAPE;
   GemmParams q = p;
   q.M_total = p.M; q.tail_begin = p.M; q.main_tiles = 0;
+  q.ldw = (NPASS == 3) ? 2 * p.K : p.K;
   int tail_blocks = 0;
   const int tail = p.M % 128;
   if (g_tail_rows && tail > 0 && tail <= 8 && p.M > 128 && p.K % 64 == 0) {
@@ -58,11 +60,11 @@ static int launch_ws(const GemmParams& p, hipStream_t s) {
   q.main_tiles = tiles_m * tiles_n;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_ws_kernel<NPASS, BK, NS, EPI, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_ws_kernel<NPASS, BK, NS, EPI, AMODE, AIL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return OVM_ERR_HIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_ws_kernel<NPASS, BK, NS, EPI, AMODE>), dim3(q.main_tiles + tail_blocks), dim3(512), smem, s, q);
+  hipLaunchKernelGGL((gemm_ws_kernel<NPASS, BK, NS, EPI, AMODE, AIL>), dim3(q.main_tiles + tail_blocks), dim3(512), smem, s, q);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 
@@ -86,6 +88,10 @@ static int launch_prec(const GemmParams& p, int npass, hipStream_t s) {
   const long tiles_m = (g_tail_rows && tail_rows > 0 && tail_rows <= 8 && p.M > 128 && p.K % 64 == 0) ? p.M / 128 : (p.M + 127) / 128;
   const long tiles = tiles_m * ((p.N + 127) / 128);
   const int st = g_force_stages ? g_force_stages : (tiles <= 512 ? 6 : 2);
+  if (npass == 3 && p.a_il) {                      // interleaved activations: the two default variants only
+    if (st == 6 || st == 5) return launch_ws<3, 32, 3, EPI, AMODE, true>(p, s);
+    return launch_one<3, 32, 128, 2, EPI, AMODE, true>(p, s);
+  }
   if (st == 5) return npass == 3 ? launch_ws<3, 32, 4, EPI, AMODE>(p, s) : launch_ws<1, 64, 4, EPI, AMODE>(p, s);
   if (st == 6) return npass == 3 ? launch_ws<3, 32, 3, EPI, AMODE>(p, s) : launch_ws<1, 64, 3, EPI, AMODE>(p, s);
   if (npass == 3) {

@@ -23,7 +23,12 @@ enum Epi { EPI_STORE = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_QKV = 3, EPI_PATCH = 
 
 struct GemmParams {
   const half_t* Ahi; const half_t* Alo; int lda;
-  const half_t* Whi; const half_t* Wlo;          // [Npad][K], Npad multiple of 128, zero rows beyond N
+  // W: [Npad][K] fp16 (one-pass mode), or - split mode - interleaved [Npad][K/32][hi 32 | lo 32] (Wlo = Whi + 32, row
+  // stride 2K): one 128-byte line per row and 32-wide k-step holds both parts, so an LDS-DMA wave-instruction fetches 8 rows x
+  // 128 B instead of 16 rows x 64 B (measured 1.56x the LDS-DMA rate, scratch/micro/dma_bench.hip). Npad multiple of 128.
+  const half_t* Whi; const half_t* Wlo;
+  int ldw;                                        // set by the launcher: W row stride in halves (K or 2K)
+  int a_il;                                       // split mode: A is interleaved the same way (Alo = Ahi + 32, lda = 2K)
   int M, N, K;
   // A_CONV3X3: A is [B][cH+2][cW+2][cC] fp16 with a zero border, m = (b*cH + y)*cW + x
   int cH, cW, cC;
@@ -70,6 +75,37 @@ __device__ __forceinline__ uint32_t a_k_offset(const GemmParams& p, int k0) {
   const int tap = k0 / p.cC, c0 = k0 - tap * p.cC;
   const int dy = tap / 3, dx = tap - dy * 3;
   return (uint32_t)((dy * (p.cW + 2) + dx) * p.cC + c0);
+}
+
+
+// Staging geometry of one operand side (A or W) of a k-tile in LDS.
+//   one-pass:            rows of BK*2 bytes (BK = 64: 128 B), one part
+//   split, plain arrays: rows of 64 B (BK = 32), two parts (hi rows, then lo rows)
+//   split, interleaved:  rows of 128 B = [hi 32 | lo 32], one part
+template <int NPASS, int BK, bool IL>
+struct Side {
+  static constexpr int ROWB = IL ? 128 : BK * 2;
+  static constexpr int PARTS = (NPASS == 3 && !IL) ? 2 : 1;
+  static constexpr int RPI = 1024 / ROWB;                    // rows one 1-KiB wave-instruction covers
+  static constexpr int CH = ROWB / 16;                       // 16-byte chunks per row
+  static constexpr int KSTEP = IL ? 64 : BK;                 // halves a k-tile advances inside a row
+  __host__ __device__ static constexpr int bytes(int rows) { return rows * ROWB * PARTS; }
+  __device__ __forceinline__ static int swz(int row, int c) { return ROWB == 128 ? swz_slot<64>(row, c) : swz_slot<32>(row, c); }
+  // byte offsets of the hi / lo fragment (8 halves at k = 32 kk + 8 fq) of `row`, relative to the side's region
+  __device__ __forceinline__ static int frag_hi(int row, int kk, int fq) { return row * ROWB + swz(row, IL ? fq : kk * 4 + fq) * 16; }
+  __device__ __forceinline__ static int frag_lo(int rows, int row, int kk, int fq) {
+    return IL ? row * ROWB + swz(row, 4 + fq) * 16 : rows * ROWB + row * ROWB + swz(row, kk * 4 + fq) * 16;
+  }
+};
+template <int AMODE, bool AIL>
+__device__ __forceinline__ uint32_t a_row_off(const GemmParams& p, int m) {
+  const uint32_t o = a_row_offset<AMODE>(p, m);
+  return (AIL && AMODE != A_ROWMAJOR) ? o * 2 : o;           // row-major: the caller's lda already is 2K
+}
+template <int AMODE, bool AIL>
+__device__ __forceinline__ uint32_t a_k_off(const GemmParams& p, int k0) {
+  const uint32_t o = a_k_offset<AMODE>(p, k0);
+  return AIL ? o * 2 : o;                                    // k0 is a multiple of 32: group g starts at 64 g
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -175,24 +211,22 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32
   }
 }
 
-template <int NPASS, int EPI, int AMODE>
+template <int NPASS, int EPI, int AMODE, bool AIL>
 __device__ __forceinline__ void gemm_tail_body(const GemmParams& p, int tb);
 
-template <int NPASS, int BK, int BM, int NSTAGE, int EPI, int AMODE>
+template <int NPASS, int BK, int BM, int NSTAGE, int EPI, int AMODE, bool AIL = false>
 __global__ __launch_bounds__(BM * 2) void gemm_kernel(const GemmParams p) {
-  if ((int)blockIdx.x >= p.main_tiles) { gemm_tail_body<NPASS, EPI, AMODE>(p, (int)blockIdx.x - p.main_tiles); return; }
+  if ((int)blockIdx.x >= p.main_tiles) { gemm_tail_body<NPASS, EPI, AMODE, AIL>(p, (int)blockIdx.x - p.main_tiles); return; }
   // Block tile BM x 128 (BM = 128: 4 waves, BM = 256: 8 waves); every wave owns a 64 x 64 sub-tile.
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = BM / 32;                     // waves per block
-  constexpr int ROWB = BK * 2;                    // bytes per LDS row
-  constexpr int PART_A = BM * ROWB, PART_W = 128 * ROWB;
-  constexpr int STAGE = (PART_A + PART_W) * ((NPASS == 3) ? 2 : 1);
-  constexpr int OFF_AH = 0, OFF_WH = PART_A, OFF_AL = PART_A + PART_W, OFF_WL = 2 * PART_A + PART_W;
-  constexpr int ROWS_PER_INSTR = 1024 / ROWB;     // rows one wave-wide DMA covers (8 or 16)
-  constexpr int CH = ROWB / 16;                   // 16-byte chunks per row (8 or 4)
-  constexpr int IA = BM / ROWS_PER_INSTR / NW;    // A DMA instructions per wave per part
-  constexpr int IW = (128 / ROWS_PER_INSTR + NW - 1) / NW;   // W DMA instructions per wave per part (may be partial)
-  constexpr int NIW = 128 / ROWS_PER_INSTR;       // total W instructions per part
+  using SA = Side<NPASS, BK, AIL && NPASS == 3>;
+  using SW = Side<NPASS, BK, NPASS == 3>;         // split-mode weights are always interleaved
+  constexpr int OFF_A = 0, OFF_W = SA::bytes(BM);
+  constexpr int STAGE = SA::bytes(BM) + SW::bytes(128);
+  constexpr int IA = BM / SA::RPI / NW;           // A DMA instructions per wave per part
+  constexpr int NIW = 128 / SW::RPI;              // W DMA instructions per part, whole workgroup
+  constexpr int IW = (NIW + NW - 1) / NW;         // ... per wave (may be partial)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_m = (p.M + BM - 1) / BM;
@@ -214,36 +248,36 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
   for (int t = 0; t < IA; ++t) {
     const int instr = wave + NW * t;
-    const int row = instr * ROWS_PER_INSTR + lane / CH;
-    const int chunk = swz_slot<BK>(row, lane % CH);
+    const int row = instr * SA::RPI + lane / SA::CH;
+    const int chunk = SA::swz(row, lane % SA::CH);
     int m = m0 + row; if (m > p.M - 1) m = p.M - 1;
-    aoff[t] = a_row_offset<AMODE>(p, m) + chunk * 8;
+    aoff[t] = a_row_off<AMODE, AIL && NPASS == 3>(p, m) + chunk * 8;
   }
 #pragma unroll
   for (int t = 0; t < IW; ++t) {
     const int instr = wave + NW * t;
-    const int row = (instr % NIW) * ROWS_PER_INSTR + lane / CH;
-    const int chunk = swz_slot<BK>(row, lane % CH);
-    woff[t] = (uint32_t)(n0 + row) * (uint32_t)p.K + chunk * 8;
+    const int row = (instr % NIW) * SW::RPI + lane / SW::CH;
+    const int chunk = SW::swz(row, lane % SW::CH);
+    woff[t] = (uint32_t)(n0 + row) * (uint32_t)p.ldw + chunk * 8;
   }
 
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * STAGE;
-    const uint32_t ak = a_k_offset<AMODE>(p, kt * BK);
-    const uint32_t wk = (uint32_t)(kt * BK);
+    const uint32_t ak = a_k_off<AMODE, AIL && NPASS == 3>(p, kt * BK);
+    const uint32_t wk = (uint32_t)(kt * SW::KSTEP);
 #pragma unroll
     for (int t = 0; t < IA; ++t) {
-      char* dst = base + (wave + NW * t) * 1024;
-      glds16(p.Ahi + aoff[t] + ak, dst + OFF_AH);
-      if (NPASS == 3) glds16(p.Alo + aoff[t] + ak, dst + OFF_AL);
+      char* dst = base + OFF_A + (wave + NW * t) * 1024;
+      glds16(p.Ahi + aoff[t] + ak, dst);
+      if (SA::PARTS == 2) glds16(p.Alo + aoff[t] + ak, dst + BM * SA::ROWB);
     }
 #pragma unroll
     for (int t = 0; t < IW; ++t) {
       const int instr = wave + NW * t;
       if (instr < NIW) {                           // wave-uniform
-        char* dst = base + instr * 1024;
-        glds16(p.Whi + woff[t] + wk, dst + OFF_WH);
-        if (NPASS == 3) glds16(p.Wlo + woff[t] + wk, dst + OFF_WL);
+        char* dst = base + OFF_W + instr * 1024;
+        glds16(p.Whi + woff[t] + wk, dst);
+        if (SW::PARTS == 2) glds16(p.Wlo + woff[t] + wk, dst + 128 * SW::ROWB);
       }
     }
   };
@@ -256,7 +290,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const GemmParams p) {
 
   const int nk = p.K / BK;
   // glds instructions one wave issues per stage (for the counted vmcnt of the 3-stage ring)
-  constexpr int PER_STAGE = (IA + ((NIW >= NW) ? IW : 0)) * ((NPASS == 3) ? 2 : 1);
+  constexpr int PER_STAGE = IA * SA::PARTS + ((NIW >= NW) ? IW : 0) * SW::PARTS;
   static_assert(NSTAGE == 2 || (NIW % NW == 0 || NIW < NW), "3-stage ring needs a wave-uniform DMA count");
   // s_waitcnt immediate: vmcnt = N, expcnt / lgkmcnt untouched
   constexpr int WAIT_ONE_STAGE = (PER_STAGE & 0xF) | (7 << 4) | (15 << 8) | ((PER_STAGE >> 4) << 14);
@@ -266,18 +300,15 @@ __global__ __launch_bounds__(BM * 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
       half8 ah[4], wh[4], al[4], wl[4];
-      const int chunk = kk * 4 + fq;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int ra = wm * 64 + i * 16 + fr;
         const int rw = wn * 64 + i * 16 + fr;
-        const int oa = ra * ROWB + swz_slot<BK>(ra, chunk) * 16;
-        const int ow = rw * ROWB + swz_slot<BK>(rw, chunk) * 16;
-        ah[i] = *(const half8*)(base + OFF_AH + oa);
-        wh[i] = *(const half8*)(base + OFF_WH + ow);
+        ah[i] = *(const half8*)(base + OFF_A + SA::frag_hi(ra, kk, fq));
+        wh[i] = *(const half8*)(base + OFF_W + SW::frag_hi(rw, kk, fq));
         if (NPASS == 3) {
-          al[i] = *(const half8*)(base + OFF_AL + oa);
-          wl[i] = *(const half8*)(base + OFF_WL + ow);
+          al[i] = *(const half8*)(base + OFF_A + SA::frag_lo(BM, ra, kk, fq));
+          wl[i] = *(const half8*)(base + OFF_W + SW::frag_lo(128, rw, kk, fq));
         }
       }
 #pragma unroll
@@ -351,20 +382,18 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   __builtin_amdgcn_s_waitcnt((N & 0xF) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
 }
 
-template <int NPASS, int BK, int NS, int EPI, int AMODE>
+template <int NPASS, int BK, int NS, int EPI, int AMODE, bool AIL = false>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmParams p) {
-  if ((int)blockIdx.x >= p.main_tiles) { gemm_tail_body<NPASS, EPI, AMODE>(p, (int)blockIdx.x - p.main_tiles); return; }
+  if ((int)blockIdx.x >= p.main_tiles) { gemm_tail_body<NPASS, EPI, AMODE, AIL>(p, (int)blockIdx.x - p.main_tiles); return; }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 128, NPW = 4;
-  constexpr int ROWB = BK * 2;
-  constexpr int PART_A = BM * ROWB, PART_W = 128 * ROWB;
-  constexpr int STAGE = (PART_A + PART_W) * ((NPASS == 3) ? 2 : 1);
-  constexpr int OFF_AH = 0, OFF_WH = PART_A, OFF_AL = PART_A + PART_W, OFF_WL = 2 * PART_A + PART_W;
-  constexpr int ROWS_PER_INSTR = 1024 / ROWB;
-  constexpr int CH = ROWB / 16;
-  constexpr int IA = BM / ROWS_PER_INSTR / NPW;
-  constexpr int IW = 128 / ROWS_PER_INSTR / NPW;
-  constexpr int PER_STAGE = (IA + IW) * ((NPASS == 3) ? 2 : 1);      // DMA pieces one producer wave issues per k-tile
+  using SA = Side<NPASS, BK, AIL && NPASS == 3>;
+  using SW = Side<NPASS, BK, NPASS == 3>;
+  constexpr int OFF_A = 0, OFF_W = SA::bytes(BM);
+  constexpr int STAGE = SA::bytes(BM) + SW::bytes(128);
+  constexpr int IA = BM / SA::RPI / NPW;
+  constexpr int IW = 128 / SW::RPI / NPW;
+  constexpr int PER_STAGE = IA * SA::PARTS + IW * SW::PARTS;        // DMA pieces one producer wave issues per k-tile
   static_assert(NS >= 3 && NS <= 4 && (NS - 2) * PER_STAGE < 64, "ring depth vs vmcnt range");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -387,32 +416,32 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmParams p) {
     uint32_t aoff[IA], woff[IW];
 #pragma unroll
     for (int t = 0; t < IA; ++t) {
-      const int row = (pw + NPW * t) * ROWS_PER_INSTR + lane / CH;
-      const int chunk = swz_slot<BK>(row, lane % CH);
+      const int row = (pw + NPW * t) * SA::RPI + lane / SA::CH;
+      const int chunk = SA::swz(row, lane % SA::CH);
       int m = m0 + row; if (m > p.M - 1) m = p.M - 1;
-      aoff[t] = a_row_offset<AMODE>(p, m) + chunk * 8;
+      aoff[t] = a_row_off<AMODE, AIL && NPASS == 3>(p, m) + chunk * 8;
     }
 #pragma unroll
     for (int t = 0; t < IW; ++t) {
-      const int row = (pw + NPW * t) * ROWS_PER_INSTR + lane / CH;
-      const int chunk = swz_slot<BK>(row, lane % CH);
-      woff[t] = (uint32_t)(n0 + row) * (uint32_t)p.K + chunk * 8;
+      const int row = (pw + NPW * t) * SW::RPI + lane / SW::CH;
+      const int chunk = SW::swz(row, lane % SW::CH);
+      woff[t] = (uint32_t)(n0 + row) * (uint32_t)p.ldw + chunk * 8;
     }
     auto stage = [&](int slot, int kt) {
       char* base = smem + slot * STAGE;
-      const uint32_t ak = a_k_offset<AMODE>(p, kt * BK);
-      const uint32_t wk = (uint32_t)(kt * BK);
+      const uint32_t ak = a_k_off<AMODE, AIL && NPASS == 3>(p, kt * BK);
+      const uint32_t wk = (uint32_t)(kt * SW::KSTEP);
 #pragma unroll
       for (int t = 0; t < IA; ++t) {
-        char* dst = base + (pw + NPW * t) * 1024;
-        glds16(p.Ahi + aoff[t] + ak, dst + OFF_AH);
-        if (NPASS == 3) glds16(p.Alo + aoff[t] + ak, dst + OFF_AL);
+        char* dst = base + OFF_A + (pw + NPW * t) * 1024;
+        glds16(p.Ahi + aoff[t] + ak, dst);
+        if (SA::PARTS == 2) glds16(p.Alo + aoff[t] + ak, dst + BM * SA::ROWB);
       }
 #pragma unroll
       for (int t = 0; t < IW; ++t) {
-        char* dst = base + (pw + NPW * t) * 1024;
-        glds16(p.Whi + woff[t] + wk, dst + OFF_WH);
-        if (NPASS == 3) glds16(p.Wlo + woff[t] + wk, dst + OFF_WL);
+        char* dst = base + OFF_W + (pw + NPW * t) * 1024;
+        glds16(p.Whi + woff[t] + wk, dst);
+        if (SW::PARTS == 2) glds16(p.Wlo + woff[t] + wk, dst + 128 * SW::ROWB);
       }
     };
 #pragma unroll
@@ -442,22 +471,24 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   constexpr int NF = 4 * (BK / 32);                            // fragments per operand part per k-tile
   half8 ahA[NF], whA[NF], alA[NF], wlA[NF], ahB[NF], whB[NF], alB[NF], wlB[NF];
-  int oa[NF], ow[NF];
+  int oah[NF], oal[NF], owh[NF], owl[NF];
 #pragma unroll
   for (int kk = 0; kk < BK / 32; ++kk)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int ra = wm * 64 + i * 16 + fr, rw = wn * 64 + i * 16 + fr;
-      oa[kk * 4 + i] = ra * ROWB + swz_slot<BK>(ra, kk * 4 + fq) * 16;
-      ow[kk * 4 + i] = rw * ROWB + swz_slot<BK>(rw, kk * 4 + fq) * 16;
+      oah[kk * 4 + i] = OFF_A + SA::frag_hi(ra, kk, fq);
+      oal[kk * 4 + i] = OFF_A + SA::frag_lo(BM, ra, kk, fq);
+      owh[kk * 4 + i] = OFF_W + SW::frag_hi(rw, kk, fq);
+      owl[kk * 4 + i] = OFF_W + SW::frag_lo(128, rw, kk, fq);
     }
 #define OVM_WS_READ(S, base)                                                            \
   _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                      \
-    ah##S[f] = *(const half8*)((base) + OFF_AH + oa[f]);                                \
-    wh##S[f] = *(const half8*)((base) + OFF_WH + ow[f]);                                \
+    ah##S[f] = *(const half8*)((base) + oah[f]);                                        \
+    wh##S[f] = *(const half8*)((base) + owh[f]);                                        \
     if (NPASS == 3) {                                                                   \
-      al##S[f] = *(const half8*)((base) + OFF_AL + oa[f]);                              \
-      wl##S[f] = *(const half8*)((base) + OFF_WL + ow[f]);                              \
+      al##S[f] = *(const half8*)((base) + oal[f]);                                      \
+      wl##S[f] = *(const half8*)((base) + owl[f]);                                      \
     }                                                                                   \
   }
 #define OVM_WS_MFMA(S)                                                                  \
@@ -560,7 +591,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmParams p) {
 // 256 CUs, so up to 8 leftover rows are computed by this wave-per-4-columns dot-product kernel instead
 // (fp32 FMA on the reconstructed hi+lo operands, same epilogues).
 // ---------------------------------------------------------------------------------------------
-template <int NPASS, int EPI, int AMODE>
+template <int NPASS, int EPI, int AMODE, bool AIL>
 __device__ __forceinline__ void gemm_tail_body(const GemmParams& p, int tb) {
   // tb = tail workgroup index; every wave computes 4 consecutive columns of one leftover row
   const int lane = threadIdx.x & 63;
@@ -570,10 +601,11 @@ __device__ __forceinline__ void gemm_tail_body(const GemmParams& p, int tb) {
   const int n = ((tb - row * groups_per_row) * waves + (threadIdx.x >> 6)) * 4;
   const int m = p.tail_begin + row;
   if (n >= p.N || m >= p.M_total) return;
-  const uint32_t arow = a_row_offset<AMODE>(p, m);
+  constexpr bool AI = AIL && NPASS == 3, WI = NPASS == 3;
+  const uint32_t arow = a_row_off<AMODE, AI>(p, m);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int k0 = lane * 8; k0 < p.K; k0 += 512) {
-    const uint32_t ao = arow + a_k_offset<AMODE>(p, k0 & ~63) + (k0 & 63);
+    const uint32_t ao = arow + a_k_off<AMODE, AI>(p, k0 & ~63) + (AI ? ((k0 & 32) * 2 + (k0 & 31)) : (k0 & 63));
     const half8 ah = *(const half8*)(p.Ahi + ao);
     float a[8];
 #pragma unroll
@@ -585,7 +617,7 @@ __device__ __forceinline__ void gemm_tail_body(const GemmParams& p, int tb) {
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const size_t wo = (size_t)(n + r) * p.K + k0;
+      const size_t wo = (size_t)(n + r) * p.ldw + (WI ? ((size_t)(k0 >> 5) * 64 + (k0 & 31)) : (size_t)k0);
       const half8 wh = *(const half8*)(p.Whi + wo);
       float w[8];
 #pragma unroll

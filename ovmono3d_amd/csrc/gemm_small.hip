@@ -66,8 +66,12 @@ __global__ __launch_bounds__(256) void gemm_f32a_kernel(const SmallGemmParams p)
   const int row = tid >> 2, q = tid & 3;
   int am = m0 + row; if (am > p.M - 1) am = p.M - 1;
   const float* ap = p.A + (size_t)am * p.lda + q * 16;
-  const half_t* whp = p.Whi + (size_t)(n0 + row) * p.Kpad + q * 16;
-  const half_t* wlp = p.Wlo + (size_t)(n0 + row) * p.Kpad + q * 16;
+  // weights: one-pass [Npad][Kpad]; split mode the interleaved image [Npad][Kpad/32][hi 32 | lo 32] (k0 is a multiple of 64, q*16 of
+  // 16: the 16 halves a thread moves never straddle a 32-group)
+  const half_t* whp = (NPASS == 3) ? p.Whi + (size_t)(n0 + row) * 2 * p.Kpad + (q >> 1) * 64 + (q & 1) * 16
+                                   : p.Whi + (size_t)(n0 + row) * p.Kpad + q * 16;
+  const half_t* wlp = whp + 32;
+  const int wkm = (NPASS == 3) ? 2 : 1;                     // k0 -> offset multiplier inside a row
   struct Stage { float4 a0, a1, a2, a3; uint4 wh0, wh1, wl0, wl1; };
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   auto gload = [&](Stage& r, int k0) {
@@ -76,8 +80,8 @@ __global__ __launch_bounds__(256) void gemm_f32a_kernel(const SmallGemmParams p)
     r.a1 = (kq + 4 < p.K) ? *(const float4*)(ap + k0 + 4) : z4;
     r.a2 = (kq + 8 < p.K) ? *(const float4*)(ap + k0 + 8) : z4;
     r.a3 = (kq + 12 < p.K) ? *(const float4*)(ap + k0 + 12) : z4;
-    r.wh0 = *(const uint4*)(whp + k0); r.wh1 = *(const uint4*)(whp + k0 + 8);
-    if (NPASS == 3) { r.wl0 = *(const uint4*)(wlp + k0); r.wl1 = *(const uint4*)(wlp + k0 + 8); }
+    r.wh0 = *(const uint4*)(whp + k0 * wkm); r.wh1 = *(const uint4*)(whp + k0 * wkm + 8);
+    if (NPASS == 3) { r.wl0 = *(const uint4*)(wlp + k0 * wkm); r.wl1 = *(const uint4*)(wlp + k0 * wkm + 8); }
   };
   const int woff0 = row * 128 + swz_slot<64>(row, 2 * q) * 16;
   const int woff1 = row * 128 + swz_slot<64>(row, 2 * q + 1) * 16;

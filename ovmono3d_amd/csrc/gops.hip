@@ -39,13 +39,19 @@ __global__ void split_pad_kernel(const float* __restrict__ x, int ldx, int M, in
   if (lo) lo[i] = l;
 }
 
+// lo == nullptr: one-pass image [Npad][Kpad]; else the interleaved split image [Npad][Kpad/32][hi 32 | lo 32] (lo = hi + 32)
 __global__ void pack_weight_kernel(const float* __restrict__ w, int N, int K, int Npad, int Kpad, half_t* __restrict__ hi, half_t* __restrict__ lo) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)Npad * Kpad) return;
   const int k = (int)(i % Kpad); const int n = (int)(i / Kpad);
   float v = (n < N && k < K) ? w[(size_t)n * K + k] : 0.f;
   half_t h, l; split_f16(v, h, l);
-  hi[i] = h; lo[i] = l;
+  if (lo) {
+    const size_t o = (size_t)n * 2 * Kpad + (size_t)(k >> 5) * 64 + (k & 31);
+    hi[o] = h; hi[o + 32] = l;
+  } else {
+    hi[i] = h;
+  }
 }
 
 // y = LayerNorm(x (+ residual)) over the last dim; one wave per row, any D (looped)
@@ -355,11 +361,12 @@ extern "C" {
 
 int ovm_g_pack_weight(const float* w, int32_t N, int32_t K, int32_t Kpad, uint16_t* hi, uint16_t* lo, ovm_stream_t stream) {
   const int Npad = (N + 127) / 128 * 128;
+  if (lo && (lo != hi + 32 || Kpad % 32 != 0)) return OVM_ERR_INVALID;      // split image: lo interleaved 32 halves after hi
   hipLaunchKernelGGL(pack_weight_kernel, g1((long)Npad * Kpad), dim3(256), 0, (hipStream_t)stream, w, N, K, Npad, Kpad, (half_t*)hi, (half_t*)lo);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 
-// y[M][N] (row stride ldy) = act(x[M][K] W^T + bias) (+ residual). W packed [Npad][Kpad] split fp16.
+// y[M][N] (row stride ldy) = act(x[M][K] W^T + bias) (+ residual). W packed by ovm_g_pack_weight (split mode: interleaved image, w_lo = w_hi + 32).
 int ovm_g_linear(const float* x, int32_t ldx, int32_t M, int32_t K, const uint16_t* w_hi, const uint16_t* w_lo, int32_t N, int32_t Kpad,
                  const float* bias, int32_t act, const float* residual, int32_t ldr, float* y, int32_t ldy, int32_t precision,
                  ovm_stream_t stream) {

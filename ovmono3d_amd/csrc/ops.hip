@@ -71,8 +71,33 @@ int ovm_op_gemm(const uint16_t* a_hi, const uint16_t* a_lo, int32_t lda, const u
   GemmParams p; memset(&p, 0, sizeof(p));
   p.Ahi = (const half_t*)a_hi; p.Alo = (const half_t*)a_lo; p.lda = lda;
   p.Whi = (const half_t*)w_hi; p.Wlo = (const half_t*)w_lo;
+  if (precision == 3) {
+    if (w_lo != w_hi + 32) return OVM_ERR_INVALID;            // split weights are an interleaved image (ovm_op_interleave)
+    p.a_il = (a_lo == a_hi + 32);                             // activations: either layout
+  }
   p.M = M; p.N = N; p.K = K; p.bias = bias; p.relu = relu; p.C = c; p.ldc = ldc;
   return launch_gemm(p, precision, EPI_STORE, A_ROWMAJOR, (hipStream_t)stream);
+}
+
+namespace {
+__global__ void interleave_kernel(const half_t* __restrict__ hi, const half_t* __restrict__ lo, long rows, int K, half_t* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * K) return;
+  const long r = i / K; const int k = (int)(i - r * K);
+  const size_t o = (size_t)r * 2 * K + (size_t)(k >> 5) * 64 + (k & 31);
+  out[o] = hi[i];
+  out[o + 32] = lo[i];
+}
+}  // namespace
+
+// hi, lo [rows][K] (K % 32 == 0) -> out [rows][K/32][hi 32 | lo 32], the operand image of the split-mode GEMM
+int ovm_op_interleave(const uint16_t* hi, const uint16_t* lo, int64_t rows, int32_t K, uint16_t* out, ovm_stream_t stream) {
+  if (rows <= 0) return OVM_OK;
+  if (!hi || !lo || !out || K % 32 != 0) return OVM_ERR_INVALID;
+  const long n = (long)rows * K;
+  hipLaunchKernelGGL(interleave_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)hi, (const half_t*)lo,
+                     (long)rows, K, (half_t*)out);
+  return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 
 int ovm_op_layernorm(const float* x, int32_t M, int32_t D, const float* gamma, const float* beta, float eps, float* y,

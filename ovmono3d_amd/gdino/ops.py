@@ -47,9 +47,14 @@ class Ops:
         N, K = w.shape
         Kpad = (K + 63) // 64 * 64
         Npad = (N + 127) // 128 * 128
-        hi = torch.empty((Npad, Kpad), dtype=torch.float16, device=self.dev)
-        lo = torch.empty((Npad, Kpad), dtype=torch.float16, device=self.dev)
-        self._chk(self.L.ovm_g_pack_weight(w.data_ptr(), N, K, Kpad, hi.data_ptr(), lo.data_ptr(), self._s()), "ovm_g_pack_weight")
+        if self.prec == 3:
+            # split mode: one interleaved image [Npad][Kpad/32][hi 32 | lo 32]; lo is the same buffer 32 halves in
+            hi = torch.empty((Npad, 2 * Kpad), dtype=torch.float16, device=self.dev)
+            lo = hi.view(-1)[32:]
+        else:
+            hi, lo = torch.empty((Npad, Kpad), dtype=torch.float16, device=self.dev), None
+        self._chk(self.L.ovm_g_pack_weight(w.data_ptr(), N, K, Kpad, hi.data_ptr(), lo.data_ptr() if lo is not None else None, self._s()),
+                  "ovm_g_pack_weight")
         return PackedW(hi, lo, N, K, Kpad, self.f32(bias) if bias is not None else None)
 
     def linear(self, x: torch.Tensor, W: PackedW, act: int = 0, residual: Optional[torch.Tensor] = None,
@@ -60,7 +65,7 @@ class Ops:
         M = x2.shape[0]
         y = out if out is not None else self.empty(M, W.N)
         r = residual.reshape(M, W.N) if residual is not None else None
-        self._chk(self.L.ovm_g_linear(x2.data_ptr(), x2.stride(0), M, W.K, W.hi.data_ptr(), W.lo.data_ptr(), W.N, W.Kpad,
+        self._chk(self.L.ovm_g_linear(x2.data_ptr(), x2.stride(0), M, W.K, W.hi.data_ptr(), W.lo.data_ptr() if W.lo is not None else None, W.N, W.Kpad,
                                       W.bias.data_ptr() if W.bias is not None else None, act,
                                       r.data_ptr() if r is not None else None, r.stride(0) if r is not None else 0,
                                       y.data_ptr(), y.stride(0), self.prec, self._s()), "ovm_g_linear")

@@ -29,6 +29,25 @@ def _split(x):
     return hi, lo
 
 
+def _interleave(hi, lo):
+    """[rows][K] hi, lo -> the interleaved operand image [rows][K/32][hi 32 | lo 32] of the split-precision GEMM."""
+    rows, K = hi.shape
+    out = torch.empty(rows, 2 * K, dtype=torch.float16, device=hi.device)
+    assert _lib().ovm_op_interleave(hi.data_ptr(), lo.data_ptr(), rows, K, out.data_ptr(), _stream()) == 0
+    return out
+
+
+def _gemm_args(ah, al, wh, wl, K, precision, a_interleaved=False):
+    """(a_hi, a_lo, lda, w_hi, w_lo, keepalive) for ovm_op_gemm: split weights are always an interleaved image."""
+    if precision != 3:
+        return ah.data_ptr(), al.data_ptr(), K, wh.data_ptr(), wl.data_ptr(), ()
+    wi = _interleave(wh, wl)
+    if a_interleaved:
+        ai = _interleave(ah, al)
+        return ai.data_ptr(), ai.data_ptr() + 64, 2 * K, wi.data_ptr(), wi.data_ptr() + 64, (wi, ai)
+    return ah.data_ptr(), al.data_ptr(), K, wi.data_ptr(), wi.data_ptr() + 64, (wi,)
+
+
 def test_split_f16_roundtrip(device):
     x = torch.randn(10007, device=device) * 3
     hi, lo = _split(x)
@@ -38,8 +57,10 @@ def test_split_f16_roundtrip(device):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 300, 192), (1, 13, 1024), (4097, 384, 128), (77, 1024, 12544)])
-@pytest.mark.parametrize("precision", [1, 3])
+@pytest.mark.parametrize("precision", [1, 3, 4])
 def test_gemm_store(device, M, N, K, precision):
+    a_il = precision == 4                      # 4 = split mode with interleaved activations as well
+    precision = 3 if a_il else precision
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N)
     A = torch.randn(M, K, generator=g).to(device)
     W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(device)
@@ -50,8 +71,8 @@ def test_gemm_store(device, M, N, K, precision):
     ah, al = _split(A)
     wh, wl = _split(Wp)
     Cout = torch.full((M, N + 3), 7.0, device=device)
-    rc = _lib().ovm_op_gemm(ah.data_ptr(), al.data_ptr(), K, wh.data_ptr(), wl.data_ptr(), M, N, K, bias.data_ptr(), 1,
-                            Cout.data_ptr(), N + 3, precision, _stream())
+    a_hi, a_lo, lda, w_hi, w_lo, keep = _gemm_args(ah, al, wh, wl, K, precision, a_il)
+    rc = _lib().ovm_op_gemm(a_hi, a_lo, lda, w_hi, w_lo, M, N, K, bias.data_ptr(), 1, Cout.data_ptr(), N + 3, precision, _stream())
     assert rc == 0
     torch.cuda.synchronize()
     ref = torch.relu(A.double() @ W.double().T + bias.double()).float()
@@ -70,10 +91,10 @@ def test_gemm_exact_integers(device):
     W = (torch.arange(N * K, device=device).reshape(N, K) % 13 - 6).float()
     Wp = torch.zeros(256, K, device=device); Wp[:N] = W
     ah, al = _split(A); wh, wl = _split(Wp)
-    for precision in (1, 3):
+    for precision, a_il in ((1, False), (3, False), (3, True)):
         Cout = torch.zeros(M, N, device=device)
-        rc = _lib().ovm_op_gemm(ah.data_ptr(), al.data_ptr(), K, wh.data_ptr(), wl.data_ptr(), M, N, K, None, 0,
-                                Cout.data_ptr(), N, precision, _stream())
+        a_hi, a_lo, lda, w_hi, w_lo, keep = _gemm_args(ah, al, wh, wl, K, precision, a_il)
+        rc = _lib().ovm_op_gemm(a_hi, a_lo, lda, w_hi, w_lo, M, N, K, None, 0, Cout.data_ptr(), N, precision, _stream())
         assert rc == 0
         torch.cuda.synchronize()
         assert torch.equal(Cout, A @ W.T)
