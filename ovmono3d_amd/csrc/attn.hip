@@ -152,29 +152,36 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     const float m_new = fmaxf(m_run, mx);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
-    float psum = 0.f;
+    // packed fp32 arithmetic (v_pk_add_f32 handles two scores per lane and instruction) for the shift, the row sum and the
+    // hi/lo residual; the exponentials and the converts have no packed form
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 shift2 = {kPShift - m_new, kPShift - m_new};
+    f32x2 psum2 = {0.f, 0.f};
     half8 ph[2][2], pl[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp) {
-        float pv[8], pd[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          pv[e] = __builtin_amdgcn_exp2f(sc[i][8 * sp + e] - m_new + kPShift);
-          psum += pv[e];
-        }
-        // Probabilities are carried scaled by 2^kPShift (<= 16384, no fp16 overflow; the scale cancels in O / l). That moves
-        // the fp16 subnormal range down to 3.7e-9 of the row maximum, so both parts can use the compiler's packed converts
-        // (v_cvt_pk_f16_f32 flushes subnormal results): what a flush can drop is bounded by 4097 keys x 3.7e-9 (hi) and
-        // 4097 x 7.6e-6 x 2^-11 (lo) of the largest term - 1.5e-5 each in the worst case.
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ph[i][sp][e] = (half_t)pv[e];
-        if (NPASS == 3) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { pd[e] = pv[e] - (float)ph[i][sp][e]; pl[i][sp][e] = (half_t)pd[e]; }
+        for (int e = 0; e < 8; e += 2) {
+          f32x2 d = {sc[i][8 * sp + e], sc[i][8 * sp + e + 1]};
+          d += shift2;
+          f32x2 pv = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+          psum2 += pv;
+          // Probabilities are carried scaled by 2^kPShift (<= 16384, no fp16 overflow; the scale cancels in O / l). That moves
+          // the fp16 subnormal range down to 3.7e-9 of the row maximum, so both parts can use the compiler's packed converts
+          // (v_cvt_pk_f16_f32 flushes subnormal results): what a flush can drop is bounded by 4097 keys x 3.7e-9 (hi) and
+          // 4097 x 7.6e-6 x 2^-11 (lo) of the largest term - 1.5e-5 each in the worst case.
+          const half_t h0 = (half_t)pv[0], h1 = (half_t)pv[1];
+          ph[i][sp][e] = h0; ph[i][sp][e + 1] = h1;
+          if (NPASS == 3) {
+            const f32x2 hf = {(float)h0, (float)h1};
+            const f32x2 pd = pv - hf;
+            pl[i][sp][e] = (half_t)pd[0]; pl[i][sp][e + 1] = (half_t)pd[1];
+          }
         }
       }
+    const float psum = psum2[0] + psum2[1];
     l_run = l_run * alpha + psum;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
