@@ -92,26 +92,26 @@ __device__ __forceinline__ bool iou_gt(const float* a, const float* b, float thr
 __global__ void nms_mask_kernel(const float* __restrict__ box, const int* __restrict__ group, const int* __restrict__ gstart,
                                 const int* __restrict__ gend, int ngroups, int N, int W, float thr,
                                 unsigned long long* __restrict__ mask) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // one thread per (candidate i, 64-candidate word w): 64 IoU tests each
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.y;
-  if (i >= N) return;
-  unsigned long long* out = mask + ((size_t)b * N + i) * W;
+  if (idx >= (long)N * W) return;
+  const int i = (int)(idx / W), w = (int)(idx - (long)i * W);
+  unsigned long long* out = mask + ((size_t)b * N + i) * W + w;
   const int g = group[(size_t)b * N + i];
-  if (g < 0) { for (int w = 0; w < W; ++w) out[w] = 0ull; return; }
+  if (g < 0) { *out = 0ull; return; }
   const int st = gstart[b * ngroups + g], en = gend[b * ngroups + g];
   const float* bx = box + (size_t)b * N * 4;
-  float me[4] = {bx[i * 4], bx[i * 4 + 1], bx[i * 4 + 2], bx[i * 4 + 3]};
-  for (int w = 0; w < W; ++w) {
-    unsigned long long bits = 0ull;
-    const int j0 = st + w * 64;
-    if (j0 + 63 > i && j0 < en) {
-      for (int t = 0; t < 64; ++t) {
-        const int j = j0 + t;
-        if (j > i && j < en && group[(size_t)b * N + j] == g && iou_gt(me, bx + (size_t)j * 4, thr)) bits |= (1ull << t);
-      }
+  unsigned long long bits = 0ull;
+  const int j0 = st + w * 64;
+  if (j0 + 63 > i && j0 < en) {
+    const float me[4] = {bx[i * 4], bx[i * 4 + 1], bx[i * 4 + 2], bx[i * 4 + 3]};
+    for (int t = 0; t < 64; ++t) {
+      const int j = j0 + t;
+      if (j > i && j < en && group[(size_t)b * N + j] == g && iou_gt(me, bx + (size_t)j * 4, thr)) bits |= (1ull << t);
     }
-    out[w] = bits;
   }
+  *out = bits;
 }
 
 // one wave per (group, image): sequential greedy pass; lane w owns removed-word w
@@ -454,7 +454,7 @@ int det2d_forward(const Det2dModel& m, Det2dWorkspace& w, float* boxes, float* s
   hipLaunchKernelGGL(rpn_decode_kernel, dim3((NS + 255) / 256, B), dim3(256), 0, s, w.keys, w.rpn_o[0], w.rpn_o[1], w.rpn_o[2], gm, N,
                      m.pre_topk, m.meta, scale_clamp, w.cbox, w.cscore, w.cgroup, w.gstart, w.gend);
   // ---- per-level NMS, merge by score, keep post_topk ----
-  hipLaunchKernelGGL(nms_mask_kernel, dim3((NS + 127) / 128, B), dim3(128), 0, s, w.cbox, w.cgroup, w.gstart, w.gend, 3, NS, 16,
+  hipLaunchKernelGGL(nms_mask_kernel, dim3((NS * 16 + 127) / 128, B), dim3(128), 0, s, w.cbox, w.cgroup, w.gstart, w.gend, 3, NS, 16,
                      m.rpn_nms, w.mask);
   hipLaunchKernelGGL(nms_scan_kernel, dim3(3, B), dim3(64), 0, s, w.cgroup, w.gstart, w.gend, 3, NS, 16, w.mask, w.ckeep);
   hipLaunchKernelGGL(rpn_merge_keys_kernel, dim3((w.Nmerge + 255) / 256, B), dim3(256), 0, s, w.cscore, w.ckeep, NS, w.Nmerge, w.mkeys);
@@ -495,7 +495,7 @@ int det2d_forward(const Det2dModel& m, Det2dWorkspace& w, float* boxes, float* s
   if (hipMemsetAsync(w.gstart, 0, sizeof(int) * (size_t)B * K, s) != hipSuccess) return OVM_ERR_HIP;
   if (hipMemsetAsync(w.gend, 0, sizeof(int) * (size_t)B * K, s) != hipSuccess) return OVM_ERR_HIP;
   hipLaunchKernelGGL(seg_bounds_kernel, dim3((Nc + 255) / 256, B), dim3(256), 0, s, w.sgroup, Nc, K, w.gstart, w.gend);
-  hipLaunchKernelGGL(nms_mask_kernel, dim3((Nc + 127) / 128, B), dim3(128), 0, s, w.sbox, w.sgroup, w.gstart, w.gend, K, Nc, 16,
+  hipLaunchKernelGGL(nms_mask_kernel, dim3((Nc * 16 + 127) / 128, B), dim3(128), 0, s, w.sbox, w.sgroup, w.gstart, w.gend, K, Nc, 16,
                      m.nms_thresh, w.mask);
   hipLaunchKernelGGL(nms_scan_kernel, dim3(K, B), dim3(64), 0, s, w.sgroup, w.gstart, w.gend, K, Nc, 16, w.mask, w.skeep);
   hipLaunchKernelGGL(final_keys_kernel, dim3((Nc + 255) / 256, B), dim3(256), 0, s, w.keys, w.skeep, Nc);
@@ -571,7 +571,7 @@ int launch_nms_single(const float* boxes, const float* scores, const int* valid,
   r = sort_keys(keys, N, 1, s);
   if (!r) {
     hipLaunchKernelGGL(single_gather_kernel, dim3((N + 255) / 256), dim3(256), 0, s, keys, boxes, n, N, sbox, sgroup, gse);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3((N + 127) / 128, 1), dim3(128), 0, s, sbox, sgroup, gse, gse + 1, 1, N, W, thresh, mask);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)(((long)N * W + 127) / 128), 1), dim3(128), 0, s, sbox, sgroup, gse, gse + 1, 1, N, W, thresh, mask);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1, 1), dim3(64), 0, s, sgroup, gse, gse + 1, 1, N, W, mask, keep);
     hipLaunchKernelGGL(single_emit_kernel, dim3(1), dim3(1024), 0, s, keys, keep, n, keep_idx, n_keep);
     if (hipStreamSynchronize(s) != hipSuccess) r = OVM_ERR_HIP;
