@@ -6,6 +6,8 @@ namespace ovm {
 static int g_force_bm = 0;
 static int g_tail_rows = 1;
 static int g_force_stages = 0;
+static int g_splitk = 1;
+void gemm_set_splitk(int v) { g_splitk = v; }
 
 void gemm_set_stages(int n) { g_force_stages = n; }
 void gemm_set_force_bm(int bm) { g_force_bm = bm; }
@@ -41,6 +43,8 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 
+static float* g_splitk_ws = nullptr; static size_t g_splitk_cap = 0;
+
 template <int NPASS, int BK, int NS, int EPI, int AMODE, bool AIL = false>
 static int launch_ws(const GemmParams& p, hipStream_t s) {
   constexpr int smem = NS * (128 + 128) * BK * 2 * ((NPASS == 3) ? 2 : 1);
@@ -48,16 +52,35 @@ static int launch_ws(const GemmParams& p, hipStream_t s) {
   GemmParams q = p;
   q.M_total = p.M; q.tail_begin = p.M; q.main_tiles = 0;
   q.ldw = (NPASS == 3) ? 2 * p.K : p.K;
+  q.ksplit = 1; q.kchunk = 0; q.part = nullptr;
+  const int tiles_full = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+  const int nk = p.K / BK;
+  // a thin grid with a long reduction (the RoI heads' fc1: <= 64 tiles, 392 k-tiles) leaves most CUs idle for hundreds of
+  // k-steps: split K over workgroups (deterministic: partial tiles + one reduce/epilogue pass)
+  if (g_splitk && (EPI == EPI_STORE) && tiles_full <= 64 && nk >= 64 && p.N % 4 == 0) {
+    int ks = 256 / tiles_full; if (ks > 16) ks = 16; if (ks > nk / 16) ks = nk / 16;
+    if (ks > 1) {
+      const int chunk = (nk + ks - 1) / ks;
+      ks = (nk + chunk - 1) / chunk;
+      const size_t need = (size_t)ks * p.M * p.N * sizeof(float);
+      if (g_splitk_cap < need) {
+        if (g_splitk_ws) { (void)hipDeviceSynchronize(); (void)hipFree(g_splitk_ws); }
+        g_splitk_cap = need + need / 2 + (1 << 20);
+        if (hipMalloc((void**)&g_splitk_ws, g_splitk_cap) != hipSuccess) { g_splitk_ws = nullptr; g_splitk_cap = 0; return OVM_ERR_HIP; }
+      }
+      q.ksplit = ks; q.kchunk = chunk; q.part = g_splitk_ws;
+    }
+  }
   int tail_blocks = 0;
   const int tail = p.M % 128;
-  if (g_tail_rows && tail > 0 && tail <= 8 && p.M > 128 && p.K % 64 == 0) {
+  if (q.ksplit == 1 && g_tail_rows && tail > 0 && tail <= 8 && p.M > 128 && p.K % 64 == 0) {
     q.tail_begin = p.M - tail;
     q.M = q.tail_begin;
     tail_blocks = tail * ((p.N + 4 * 8 - 1) / (4 * 8));        // 8 waves per workgroup, 4 columns per wave
   }
   const int tiles_m = (q.M + 127) / 128;
   const int tiles_n = (p.N + 127) / 128;
-  q.main_tiles = tiles_m * tiles_n;
+  q.main_tiles = tiles_m * tiles_n * q.ksplit;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)gemm_ws_kernel<NPASS, BK, NS, EPI, AMODE, AIL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -65,6 +88,10 @@ static int launch_ws(const GemmParams& p, hipStream_t s) {
     attr_set = true;
   }
   hipLaunchKernelGGL((gemm_ws_kernel<NPASS, BK, NS, EPI, AMODE, AIL>), dim3(q.main_tiles + tail_blocks), dim3(512), smem, s, q);
+  if (q.ksplit > 1) {
+    const long n = (long)p.M * (p.N / 4);
+    hipLaunchKernelGGL((splitk_epilogue_kernel<EPI>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, q);
+  }
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 

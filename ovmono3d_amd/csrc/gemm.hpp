@@ -29,6 +29,9 @@ struct GemmParams {
   const half_t* Whi; const half_t* Wlo;
   int ldw;                                        // set by the launcher: W row stride in halves (K or 2K)
   int a_il;                                       // split mode: A is interleaved the same way (Alo = Ahi + 32, lda = 2K)
+  // split-K (wave-specialised kernel, set by the launcher for thin grids with a long K): workgroup = (tile, k-slice); slices
+  // write raw fp32 partial tiles to `part` [ksplit][M][N] and splitk_epilogue_kernel sums them and applies the epilogue
+  int ksplit, kchunk; float* part;
   int M, N, K;
   // A_CONV3X3: A is [B][cH+2][cW+2][cC] fp16 with a zero border, m = (b*cH + y)*cW + x
   int cH, cW, cC;
@@ -398,8 +401,11 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_m = (p.M + BM - 1) / BM;
-  const int tiles_n = p.main_tiles / tiles_m;
-  int pid = xcd_remap(blockIdx.x, p.main_tiles);
+  const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+  const int tiles = p.main_tiles / ksplit;               // output tiles; main_tiles counts (tile, k-slice) workgroups
+  const int tiles_n = tiles / tiles_m;
+  const int ks = (int)blockIdx.x / tiles;
+  int pid = xcd_remap((int)blockIdx.x - ks * tiles, tiles);
   constexpr int GROUP_M = 8;
   const int in_group = GROUP_M * tiles_n;
   const int gid = pid / in_group;
@@ -408,7 +414,9 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmParams p) {
   const int tm = first_m + (pid % in_group) % gsz;
   const int tn = (pid % in_group) / gsz;
   const int m0 = tm * BM, n0 = tn * 128;
-  const int nk = p.K / BK;
+  const int nk_all = p.K / BK;
+  const int kt0 = (ksplit > 1) ? ks * p.kchunk : 0;       // first k-tile of this slice
+  const int nk = (ksplit > 1) ? ((nk_all - kt0 < p.kchunk) ? nk_all - kt0 : p.kchunk) : nk_all;
 
   if (wave >= 4) {
     // ---------------- producers ----------------
@@ -429,8 +437,8 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmParams p) {
     }
     auto stage = [&](int slot, int kt) {
       char* base = smem + slot * STAGE;
-      const uint32_t ak = a_k_off<AMODE, AIL && NPASS == 3>(p, kt * BK);
-      const uint32_t wk = (uint32_t)(kt * SW::KSTEP);
+      const uint32_t ak = a_k_off<AMODE, AIL && NPASS == 3>(p, (kt0 + kt) * BK);
+      const uint32_t wk = (uint32_t)((kt0 + kt) * SW::KSTEP);
 #pragma unroll
       for (int t = 0; t < IA; ++t) {
         char* dst = base + OFF_A + (pw + NPW * t) * 1024;
@@ -555,14 +563,17 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmParams p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const int mb = m0 + wm * 64, nb = n0 + wn * 64;
   bool vt_tile = false;
-  if (EPI == EPI_QKV) vt_tile = (nb / (p.N / 3)) == 2;         // wave-uniform: head blocks are 64 wide
+  if (EPI == EPI_QKV && ksplit == 1) vt_tile = (nb / (p.N / 3)) == 2;   // wave-uniform: head blocks are 64 wide
   if (!vt_tile) {
     const int col = (lane & 15) * 4;
 #pragma unroll 4
     for (int it = 0; it < 16; ++it) {
       const int row = it * 4 + (lane >> 4);
       const f32x4 v = *(const f32x4*)(tile + row * TLD + col);
-      if (mb + row < p.M) epilogue4<EPI>(p, mb + row, nb + col, v);
+      if (mb + row < p.M) {
+        if (ksplit > 1) { if (nb + col < p.N) *(f32x4*)(p.part + ((size_t)ks * p.M + mb + row) * p.N + nb + col) = v; }   // N % 4 == 0 (launcher)
+        else epilogue4<EPI>(p, mb + row, nb + col, v);
+      }
     }
   } else {
     // V^T [b][head][d][Tpad]: tokens are the contiguous axis, so lanes run along m (one 2-byte element each, 128 B per store)
@@ -583,6 +594,19 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmParams p) {
       }
     }
   }
+}
+
+
+// Sums the split-K partial tiles of gemm_ws_kernel and applies the epilogue: one thread per (row, 4 columns).
+template <int EPI>
+__global__ void splitk_epilogue_kernel(const GemmParams p) {
+  const int nq = p.N / 4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)p.M * nq) return;
+  const int m = (int)(i / nq), n = (int)(i - (long)m * nq) * 4;
+  f32x4 v = *(const f32x4*)(p.part + (size_t)m * p.N + n);
+  for (int ks = 1; ks < p.ksplit; ++ks) v += *(const f32x4*)(p.part + ((size_t)ks * p.M + m) * p.N + n);
+  epilogue4<EPI>(p, m, n, v);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -646,6 +670,7 @@ int launch_gemm(const GemmParams& p, int npass, int epi, int amode, hipStream_t 
 void gemm_set_force_bm(int bm);
 void gemm_set_tail_rows(int on);
 void gemm_set_stages(int n);
+void gemm_set_splitk(int v);
 // gemm_small.hip: fp32-A latency-oriented kernel used by the generic linear op
 bool gemm_small_supported(const float* A, int lda, int K);
 int launch_gemm_small(const float* A, int lda, int M, int K, const half_t* Whi, const half_t* Wlo, int N, int Kpad, const float* bias, int act,
