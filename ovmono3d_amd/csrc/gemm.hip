@@ -43,7 +43,7 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 
-static float* g_splitk_ws = nullptr; static size_t g_splitk_cap = 0;
+static float* g_splitk_ws_[2] = {nullptr, nullptr}; static size_t g_splitk_cap_[2] = {0, 0};
 
 template <int NPASS, int BK, int NS, int EPI, int AMODE, bool AIL = false>
 static int launch_ws(const GemmParams& p, hipStream_t s) {
@@ -63,6 +63,7 @@ static int launch_ws(const GemmParams& p, hipStream_t s) {
       const int chunk = (nk + ks - 1) / ks;
       ks = (nk + chunk - 1) / chunk;
       const size_t need = (size_t)ks * p.M * p.N * sizeof(float);
+      float*& g_splitk_ws = g_splitk_ws_[p.ws_slot & 1]; size_t& g_splitk_cap = g_splitk_cap_[p.ws_slot & 1];
       if (g_splitk_cap < need) {
         if (g_splitk_ws) { (void)hipDeviceSynchronize(); (void)hipFree(g_splitk_ws); }
         g_splitk_cap = need + need / 2 + (1 << 20);

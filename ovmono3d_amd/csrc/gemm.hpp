@@ -32,6 +32,8 @@ struct GemmParams {
   // split-K (wave-specialised kernel, set by the launcher for thin grids with a long K): workgroup = (tile, k-slice); slices
   // write raw fp32 partial tiles to `part` [ksplit][M][N] and splitk_epilogue_kernel sums them and applies the epilogue
   int ksplit, kchunk; float* part;
+  int ws_slot;                                    // which split-K workspace the launcher may use: callers that run concurrently on
+                                                  // different streams (engine = 0, generic GroundingDINO ops = 1) must not share one
   int M, N, K;
   // A_CONV3X3: A is [B][cH+2][cW+2][cC] fp16 with a zero border, m = (b*cH + y)*cW + x
   int cH, cW, cC;

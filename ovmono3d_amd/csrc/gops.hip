@@ -375,7 +375,7 @@ int ovm_g_linear(const float* x, int32_t ldx, int32_t M, int32_t K, const uint16
   // small / mid-size problems: fp32-A 64x64-tile kernel (splits x in registers, split-K on thin grids); very large grids keep
   // the 128x128 LDS-DMA kernel behind a split pre-pass
   const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-  const long small_max = g_small_max_tiles >= 0 ? g_small_max_tiles : (K <= 512 ? 100 : 64);     // measured crossover (scratch/bench_linear.py)
+  const long small_max = g_small_max_tiles >= 0 ? g_small_max_tiles : (K <= 512 ? 100 : (K >= 2048 ? 31 : 64));     // measured crossovers (scratch/bench_linear.py); long K: the MFMA kernel's split-K wins earlier
   if (tiles128 <= small_max && gemm_small_supported(x, ldx, K))
     return launch_gemm_small(x, ldx, M, K, (const half_t*)w_hi, (const half_t*)w_lo, N, Kpad, bias, act, residual, ldr, y, ldy, precision, s);
   const size_t ne = (size_t)M * Kpad;
@@ -386,6 +386,7 @@ int ovm_g_linear(const float* x, int32_t ldx, int32_t M, int32_t K, const uint16
   GemmParams p; memset(&p, 0, sizeof(p));
   p.Ahi = ahi; p.Alo = alo; p.lda = Kpad; p.Whi = (const half_t*)w_hi; p.Wlo = (const half_t*)w_lo;
   p.M = M; p.N = N; p.K = Kpad; p.bias = bias; p.relu = act; p.R = residual; p.ldr = ldr; p.C = y; p.ldc = ldy;
+  p.ws_slot = 1;                                             // this branch may run beside the engine's GEMMs on another stream
   return launch_gemm(p, precision, EPI_STORE, A_ROWMAJOR, s);
 }
 
