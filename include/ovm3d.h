@@ -151,6 +151,11 @@ int ovm_comm_destroy(void* comm);
 #define OVM_PROF_FC2 4
 #define OVM_PROF_LN 5
 #define OVM_PROF_NCAT 6
+/* Co-run mode: tells the handle that the caller runs other work on a second stream while ovm_backbone_forward executes (the
+ * GroundingDINO detector of ROIHeads3DGDINO). The attention launches then keep to one workgroup per CU so that the other stream's
+ * short kernels find free wave slots. Scheduling only: results are unchanged. */
+int ovm_set_corun(OvmHandle* handle, int32_t on);
+
 int ovm_profile_enable(OvmHandle* h, int32_t on);
 int ovm_profile_read(OvmHandle* h, float* ms /* [OVM_PROF_NCAT] */, int32_t* launches /* [OVM_PROF_NCAT] */);
 

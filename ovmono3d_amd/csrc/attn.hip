@@ -336,6 +336,8 @@ __device__ __forceinline__ void attn_tail_body(const AttnParams& p, int tb, char
 
 static int g_attn_tail = 1;
 void attn_set_tail_rows(int on) { g_attn_tail = on; }
+static int g_attn_lds_pad = 0;      // experiment: extra dynamic LDS per workgroup (lowers workgroups per CU)
+void attn_set_lds_pad(int v) { g_attn_lds_pad = v; }
 
 int launch_attention(const AttnParams& p, int npass, hipStream_t s) {
   if (p.T <= 0 || p.B <= 0) return OVM_OK;
@@ -352,7 +354,14 @@ int launch_attention(const AttnParams& p, int npass, hipStream_t s) {
   const int nqb = (pm.Tq + 127) / 128;
   pm.main_blocks = nqb * p.heads * p.B;
   const dim3 grid(pm.main_blocks + tail_blocks), block(256);
-  if (npass == 3) hipLaunchKernelGGL(attn_kernel<3>, grid, block, 2 * 4 * 64 * 128, s, pm);
+  if (npass == 3) {
+    // co-run mode: 40 KB of unused LDS per workgroup lower the occupancy to one workgroup per CU, which leaves wave slots free for
+    // the short kernels of a concurrently running stream (see AttnParams::corun)
+    const int pad = (p.corun || g_attn_lds_pad > 0) ? (g_attn_lds_pad > 0 ? g_attn_lds_pad : 40960) : 0;
+    const int smem = 2 * 4 * 64 * 128 + pad;
+    if (pad > 0) (void)hipFuncSetAttribute((const void*)attn_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(attn_kernel<3>, grid, block, smem, s, pm);
+  }
   else hipLaunchKernelGGL(attn_kernel<1>, grid, block, 2 * 2 * 64 * 128, s, pm);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }

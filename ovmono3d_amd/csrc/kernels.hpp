@@ -21,6 +21,7 @@ struct AttnParams {
   const half_t *Qhi, *Qlo, *Khi, *Klo, *Vhi, *Vlo;   // Q,K [B][h][T][64]; V^T [B][h][64][Tpad] (permuted tokens)
   half_t *Ohi, *Olo; int ldo;                        // out rows b*T + t, column head*64 + d
   int B, heads, T, Tpad;
+  int corun;                                         // another stream's short kernels run beside this launch: keep to one workgroup per CU
   int Tq, main_blocks;                               // set by the launcher: queries / workgroups of the tiled part
 };
 
@@ -70,6 +71,7 @@ int launch_depth_resize(const float* Dp, int B, int Hd, int Wd, int G, float* ou
 int launch_zero(void* p, size_t bytes, hipStream_t s);
 int launch_attention(const AttnParams& p, int npass, hipStream_t s);
 void attn_set_tail_rows(int on);
+void attn_set_lds_pad(int v);
 int launch_roi_align(const RoiParams& p, hipStream_t s);
 int launch_cube_decode(const CubeDecodeParams& p, hipStream_t s);
 int launch_compact_records(const float* rec, const int* keep, int n, int B, float* out, int* counts, hipStream_t s);

@@ -48,7 +48,7 @@ EXPORTS = [
     "ovm_create", "ovm_destroy", "ovm_last_error", "ovm_version", "ovm_backbone_forward", "ovm_cube_forward",
     "ovm_rpn_box_forward", "ovm_gather_records", "ovm_host_interp_pos_embed", "ovm_host_shard_range",
     "ovm_op_split_f16", "ovm_op_interleave", "ovm_op_gemm", "ovm_op_layernorm", "ovm_op_attention", "ovm_op_roi_align",
-    "ovm_op_cube_decode", "ovm_op_nms", "ovm_debug_copy", "ovm_profile_enable", "ovm_profile_read",
+    "ovm_op_cube_decode", "ovm_op_nms", "ovm_debug_copy", "ovm_set_corun", "ovm_profile_enable", "ovm_profile_read",
     "ovm_comm_unique_id", "ovm_comm_init", "ovm_comm_destroy", "ovm_tune_set", "ovm_gdino_postprocess", "ovm_box3d_iou", "ovm_host_pil_bilinear_coeffs", "ovm_resize_bilinear_u8",
     "ovm_g_pack_weight", "ovm_g_linear", "ovm_g_layernorm", "ovm_g_bmm", "ovm_g_bmm2", "ovm_g_softmax", "ovm_g_softmax2", "ovm_g_eltwise", "ovm_g_gather_rows",
     "ovm_g_groupnorm", "ovm_g_msdeform", "ovm_g_sine_embed", "ovm_g_normalize_image", "ovm_g_topk", "ovm_g_rowmax",
@@ -91,6 +91,7 @@ def load() -> C.CDLL:
     lib.ovm_debug_copy.argtypes = [vp, C.c_char_p, vp, i64, vp]
     lib.ovm_debug_copy.restype = i64
     lib.ovm_profile_enable.argtypes = [vp, i32]
+    lib.ovm_set_corun.argtypes = [vp, i32]
     lib.ovm_profile_read.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]
     lib.ovm_comm_unique_id.argtypes = [vp]
     lib.ovm_comm_init.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]

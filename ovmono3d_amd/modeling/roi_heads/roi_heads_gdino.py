@@ -64,7 +64,9 @@ class ROIHeads3DGDINO(ROIHeads3D):
         kernels) instead of running after it as in the reference's serial order (rcnn3d.py:97-111)."""
         self._pending = None
         if not category_list or len(images.image_sizes) != 1 or not bool(self._gdino_cfg.MODEL.AMD.GDINO_OVERLAP):
+            self.engine.set_corun(False)
             return
+        self.engine.set_corun(True)                                # the backbone's attention leaves room for the detector's kernels
         if self.detector is None:
             self.load_detector()
         from .gdino_glue import build_caption

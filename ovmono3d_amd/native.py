@@ -211,6 +211,14 @@ class Engine:
         cl = counts.cpu().tolist()            # one D2H sync per batch (reference: omni3d_evaluation.py:669)
         return rec[: sum(cl)], cl
 
+    def set_corun(self, on: bool = True) -> None:
+        """Other work runs on a second stream beside the backbone (ROIHeads3DGDINO's detector): attention keeps to one
+        workgroup per CU so that stream's short kernels are not locked out. Scheduling only."""
+        self._require()
+        if getattr(self, "_corun", None) != bool(on):
+            check(self._lib.ovm_set_corun(self._h, int(on)), self._h, "ovm_set_corun")
+            self._corun = bool(on)
+
     def profile_enable(self, on: bool = True) -> None:
         self._require()
         check(self._lib.ovm_profile_enable(self._h, int(on)), self._h, "ovm_profile_enable")
