@@ -198,9 +198,8 @@ def main():
                 "algorithmic_flops_per_launch": flops_launch,
                 "mfma_passes_per_product": 3 if args.precision == "f16x3" else 1}
     if use_gdino:
-        roofline["note"] = ("launch durations are measured while the GroundingDINO graph runs concurrently on a side stream, with the "
-                            "attention deliberately held to one workgroup per CU (co-run mode: slower kernel, faster step); "
-                            "--proposals oracle2d gives the uncontended, full-occupancy figure")
+        roofline["note"] = ("launch durations are measured while the GroundingDINO graph runs concurrently on a side stream "
+                            "(the kernels share the CUs); --proposals oracle2d gives the uncontended figure")
     kernels = {k: {"ms_per_step": round(prof[k][0] / args.steps, 4), "launches_per_step": prof[k][1] // args.steps,
                    **({"tflops": round(kf[k] * B * prof[k][1] / (prof[k][0] * 1e-3) / 1e12, 2)} if k in kf and prof[k][0] > 0 else {})}
                for k in prof}

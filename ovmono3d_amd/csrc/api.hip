@@ -705,7 +705,7 @@ int ovm_rpn_box_forward(OvmHandle* h, const OvmImage* images, int32_t B, float* 
 }
 
 // Co-run mode: the caller runs other work (the GroundingDINO detector) on a second stream while ovm_backbone_forward executes. The
-// attention launches then keep to one workgroup per CU (slower alone: 7.1 -> 9.8 ms per ViT-L image) so that the other stream's
+// attention launches then keep to one 4-wave workgroup per CU (slower alone: 6.7 -> 9.5 ms per ViT-L image) so that the other stream's
 // short kernels find free wave slots instead of queueing behind 290-us workgroups; measured end to end 28.6 -> 27.0 ms per image.
 int ovm_set_corun(OvmHandle* h, int32_t on) {
   if (!h) return OVM_ERR_INVALID;

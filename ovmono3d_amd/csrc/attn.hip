@@ -29,16 +29,17 @@ __device__ __forceinline__ void attn_tail_body(const AttnParams& p, int tb, char
 // overlap without relying on a partner wave. K tiles therefore run one tile ahead of V tiles (two 2-slot
 // LDS rings with a phase offset). Scores are in log2 units (Q is pre-scaled by dh^-0.5 * log2 e), so the
 // probabilities are a bare v_exp_f32.
-template <int NPASS>
-__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
+template <int NPASS, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x >= p.main_blocks) { attn_tail_body<NPASS>(p, (int)blockIdx.x - p.main_blocks, smem); return; }
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   constexpr int PART = 64 * 128;                       // 64 rows x 128 B
   constexpr int SLOT = PART * ((NPASS == 3) ? 2 : 1);  // hi (+ lo)
   char* const Kring = smem;                            // 2 slots
   char* const Vring = smem + 2 * SLOT;                 // 2 slots
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nqb = (p.Tq + 127) >> 7;
+  const int nqb = (p.Tq + 32 * NW - 1) / (32 * NW);
   const int bid = xcd_remap(blockIdx.x, p.main_blocks);
   const int bh = bid / nqb, qb = bid - bh * nqb;
   const int b = bh / p.heads, head = bh - b * p.heads;
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
   const size_t v_base = (size_t)bh * 64 * p.Tpad;
   const int h = lane >> 5, r = lane & 31;
 
-  int q = qb * 128 + wave * 32 + r;
+  int q = qb * (32 * NW) + wave * 32 + r;
   const bool q_ok = q < p.Tq;
   if (!q_ok) q = T - 1;
   half8 qh[4], ql[4];
@@ -57,31 +58,33 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
     if (NPASS == 3) ql[s] = *(const half8*)(p.Qlo + qk_base + (size_t)q * 64 + 16 * s + 8 * h);
   }
 
-  // DMA plan: a part is 8 wave-instructions of 8 rows x 128 B; each wave issues 2 of them per part
-  const int drow0 = wave * 8 + (lane >> 3), drow1 = drow0 + 32;
-  const int dch0 = swz128(drow0, lane & 7) * 8, dch1 = swz128(drow1, lane & 7) * 8;
+  // DMA plan: a part is 8 wave-instructions of 8 rows x 128 B; each wave issues 8 / NW of them per part
+  constexpr int PPW = 8 / NW;
+  int drow[PPW], dch[PPW];
+#pragma unroll
+  for (int t = 0; t < PPW; ++t) {
+    drow[t] = (wave + NW * t) * 8 + (lane >> 3);
+    dch[t] = swz128(drow[t], lane & 7) * 8;
+  }
   auto stageK = [&](int slot, int it) {
     char* base = Kring + slot * SLOT;
     const int k0 = it * 64;
-    int key0 = k0 + drow0; if (key0 > T - 1) key0 = T - 1;
-    int key1 = k0 + drow1; if (key1 > T - 1) key1 = T - 1;
-    const size_t o0 = qk_base + (size_t)key0 * 64 + dch0, o1 = qk_base + (size_t)key1 * 64 + dch1;
-    glds16(p.Khi + o0, base + wave * 1024);
-    glds16(p.Khi + o1, base + (wave + 4) * 1024);
-    if (NPASS == 3) {
-      glds16(p.Klo + o0, base + PART + wave * 1024);
-      glds16(p.Klo + o1, base + PART + (wave + 4) * 1024);
+#pragma unroll
+    for (int t = 0; t < PPW; ++t) {
+      int key = k0 + drow[t]; if (key > T - 1) key = T - 1;
+      const size_t o = qk_base + (size_t)key * 64 + dch[t];
+      glds16(p.Khi + o, base + (wave + NW * t) * 1024);
+      if (NPASS == 3) glds16(p.Klo + o, base + PART + (wave + NW * t) * 1024);
     }
   };
   auto stageV = [&](int slot, int it) {
     char* base = Vring + slot * SLOT;
     const int k0 = it * 64;
-    const size_t o0 = v_base + (size_t)drow0 * p.Tpad + k0 + dch0, o1 = v_base + (size_t)drow1 * p.Tpad + k0 + dch1;
-    glds16(p.Vhi + o0, base + wave * 1024);
-    glds16(p.Vhi + o1, base + (wave + 4) * 1024);
-    if (NPASS == 3) {
-      glds16(p.Vlo + o0, base + PART + wave * 1024);
-      glds16(p.Vlo + o1, base + PART + (wave + 4) * 1024);
+#pragma unroll
+    for (int t = 0; t < PPW; ++t) {
+      const size_t o = v_base + (size_t)drow[t] * p.Tpad + k0 + dch[t];
+      glds16(p.Vhi + o, base + (wave + NW * t) * 1024);
+      if (NPASS == 3) glds16(p.Vlo + o, base + PART + (wave + NW * t) * 1024);
     }
   };
   // S^T tile pair (64 keys x 32 queries) from a K slot
@@ -252,7 +255,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnParams p) {
 template <int NPASS>
 __device__ __forceinline__ void attn_tail_body(const AttnParams& p, int tb, char* smem) {
   float* sc = (float*)smem;                       // [Tpad] scores -> probabilities, in V^T's permuted token order
-  float* red = sc + p.Tpad;                       // [8]
+  float* red = sc + p.Tpad;                       // [16]: per-wave maxima, per-wave sums
+  const int nw = blockDim.x >> 6;                 // 4 or 8 waves
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntail = p.T - p.Tq;
   const int bh = tb / ntail, q = p.Tq + (tb - bh * ntail);
@@ -273,7 +277,7 @@ __device__ __forceinline__ void attn_tail_body(const AttnParams& p, int tb, char
     }
   }
   float mx = -1e30f;
-  for (int t0 = wave * 8; t0 < Tpad; t0 += 32) {
+  for (int t0 = wave * 8; t0 < Tpad; t0 += 8 * nw) {
     const int t = t0 + (lane >> 3);
     float s = 0.f;
     if (t < T) {
@@ -299,19 +303,21 @@ __device__ __forceinline__ void attn_tail_body(const AttnParams& p, int tb, char
   if (lane == 0) red[wave] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  if (nw == 8) mx = fmaxf(mx, fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
   float sum = 0.f;
-  for (int t = tid; t < Tpad; t += 256) {
+  for (int t = tid; t < Tpad; t += blockDim.x) {
     const float e = __builtin_amdgcn_exp2f(sc[t] - mx);   // scores are in log2 units; masked slots hold -1e30 -> 0
     sc[t] = e;
     sum += e;
   }
   sum = wave_sum(sum);
-  if (lane == 0) red[4 + wave] = sum;
+  if (lane == 0) red[8 + wave] = sum;
   __syncthreads();
-  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
-  // O[d] = sum_t p[t] V^T[d][t]: wave w owns d in [16w, 16w+16), lanes run along the token axis (coalesced)
-  for (int dd = 0; dd < 16; ++dd) {
-    const int d = wave * 16 + dd;
+  float tot = red[8] + red[9] + red[10] + red[11];
+  if (nw == 8) tot += red[12] + red[13] + red[14] + red[15];
+  const float inv = 1.0f / tot;
+  // O[d] = sum_t p[t] V^T[d][t]: wave w owns d = w, w + nw, ...; lanes run along the token axis (coalesced)
+  for (int d = wave; d < 64; d += nw) {
     float o = 0.f;
     for (int j = lane * 8; j < Tpad; j += 512) {
       const half8 h8 = *(const half8*)(p.Vhi + v_base + (size_t)d * Tpad + j);
@@ -338,31 +344,44 @@ static int g_attn_tail = 1;
 void attn_set_tail_rows(int on) { g_attn_tail = on; }
 static int g_attn_lds_pad = 0;      // experiment: extra dynamic LDS per workgroup (lowers workgroups per CU)
 void attn_set_lds_pad(int v) { g_attn_lds_pad = v; }
+static int g_attn_waves = 0;        // 0 = automatic (8 in co-run mode, else 4)
+void attn_set_waves(int v) { g_attn_waves = (v == 4 || v == 8) ? v : 0; }
 
 int launch_attention(const AttnParams& p, int npass, hipStream_t s) {
   if (p.T <= 0 || p.B <= 0) return OVM_OK;
   if (p.Tpad % 64 != 0 || p.Tpad < ((p.T + 63) / 64) * 64) return OVM_ERR_SHAPE;
   if (npass == 3 && (!p.Qlo || !p.Klo || !p.Vlo)) return OVM_ERR_INVALID;
   AttnParams pm = p;
-  const int tail = p.T % 128;
+  // Default: 8-wave workgroups - 256 queries share one K / V^T tile stream, i.e. half the LDS-DMA traffic of two 4-wave
+  // workgroups per CU at the same 2 waves per SIMD (7.6 -> 6.7 ms per ViT-L image). Co-run mode (another stream's short kernels
+  // run beside this launch): ONE 4-wave workgroup per CU, held there by 40 KB of unused LDS; that kernel is slower by itself
+  // (9.5 ms) but leaves half of the wave slots free, which shortens the other stream's chain by more than it costs
+  // (28.6 -> 27.5 ms per image end to end; 8 waves per CU in either arrangement do not).
+  const int nw = g_attn_waves ? g_attn_waves : (p.corun ? 4 : 8);
+  const int qpb = 32 * nw;
+  const int tail = p.T % qpb;
   int tail_blocks = 0;
   pm.Tq = p.T;
-  if (g_attn_tail && tail > 0 && tail <= 8 && p.T > 128 && (p.Tpad + 8) * 4 <= 2 * 2 * 64 * 128) {
+  if (g_attn_tail && tail > 0 && tail <= 8 && p.T > qpb && (p.Tpad + 16) * 4 <= 2 * 2 * 64 * 128) {
     pm.Tq = p.T - tail;                            // leftover queries ride along as extra workgroups
     tail_blocks = tail * p.heads * p.B;
   }
-  const int nqb = (pm.Tq + 127) / 128;
+  const int nqb = (pm.Tq + qpb - 1) / qpb;
   pm.main_blocks = nqb * p.heads * p.B;
-  const dim3 grid(pm.main_blocks + tail_blocks), block(256);
+  const dim3 grid(pm.main_blocks + tail_blocks), block(64 * nw);
+  const int pad = g_attn_lds_pad > 0 ? g_attn_lds_pad : ((p.corun && nw == 4) ? 40960 : 0);
   if (npass == 3) {
-    // co-run mode: 40 KB of unused LDS per workgroup lower the occupancy to one workgroup per CU, which leaves wave slots free for
-    // the short kernels of a concurrently running stream (see AttnParams::corun)
-    const int pad = (p.corun || g_attn_lds_pad > 0) ? (g_attn_lds_pad > 0 ? g_attn_lds_pad : 40960) : 0;
     const int smem = 2 * 4 * 64 * 128 + pad;
-    if (pad > 0) (void)hipFuncSetAttribute((const void*)attn_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipLaunchKernelGGL(attn_kernel<3>, grid, block, smem, s, pm);
-  }
-  else hipLaunchKernelGGL(attn_kernel<1>, grid, block, 2 * 2 * 64 * 128, s, pm);
+    if (nw == 8) {
+      static bool set8 = false;
+      if (!set8) { (void)hipFuncSetAttribute((const void*)attn_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set8 = true; }
+      hipLaunchKernelGGL((attn_kernel<3, 8>), grid, block, smem, s, pm);
+    } else {
+      if (pad > 0) (void)hipFuncSetAttribute((const void*)attn_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      hipLaunchKernelGGL((attn_kernel<3, 4>), grid, block, smem, s, pm);
+    }
+  } else if (nw == 8) hipLaunchKernelGGL((attn_kernel<1, 8>), grid, block, 2 * 2 * 64 * 128, s, pm);
+  else hipLaunchKernelGGL((attn_kernel<1, 4>), grid, block, 2 * 2 * 64 * 128, s, pm);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 

@@ -119,16 +119,23 @@ def _attn_ref(qkv, B, T, heads):
     return (a @ v).transpose(1, 2).reshape(B * T, D).float()
 
 
-@pytest.mark.parametrize("B,T,heads", [(1, 64, 1), (1, 257, 2), (2, 130, 2), (1, 1370, 2), (1, 4097, 1)])
+@pytest.mark.parametrize("B,T,heads", [(1, 64, 1), (1, 257, 2), (2, 130, 2), (1, 1370, 2), (1, 4097, 1), (1, 513, 2)])
 @pytest.mark.parametrize("precision", [1, 3])
-def test_attention(device, B, T, heads, precision):
+@pytest.mark.parametrize("waves", [4, 8])
+def test_attention(device, B, T, heads, precision, waves):
+    """waves = 8: the 256-query workgroup variant the engine uses in co-run mode (one workgroup per CU)."""
     g = torch.Generator().manual_seed(T)
     qkv = (torch.randn(B * T, 3 * heads * 64, generator=g) * 1.5).to(device)
     out = torch.empty(B * T, heads * 64, device=device)
-    rc = _lib().ovm_op_attention(qkv.data_ptr(), B, T, heads, out.data_ptr(), precision, _stream())
+    try:
+        assert _lib().ovm_tune_set(b"attn_waves", waves) == 0
+        rc = _lib().ovm_op_attention(qkv.data_ptr(), B, T, heads, out.data_ptr(), precision, _stream())
+        torch.cuda.synchronize()
+    finally:
+        _lib().ovm_tune_set(b"attn_waves", 0)
     assert rc == 0
     ref = _attn_ref(qkv, B, T, heads)
-    assert_close(out, ref, 5e-6 if precision == 3 else 5e-3, f"attention T={T} p{precision}")
+    assert_close(out, ref, 5e-6 if precision == 3 else 5e-3, f"attention T={T} p{precision} w{waves}")
 
 
 def test_attention_max_jump(device):
