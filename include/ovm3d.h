@@ -230,7 +230,11 @@ int ovm_g_normalize_image(const OvmImage* image, const float* mean, const float*
 int ovm_g_rowmax(const float* x, int32_t rows, int32_t cols, int32_t ld, float* out, ovm_stream_t stream);
 int ovm_g_topk(const float* scores, int32_t n, int32_t k, int32_t* out_idx, ovm_stream_t stream);
 
-/* tuning knob for experiments: key "gemm_bm" = 0 (heuristic) | 128 | 256 */
+/* Process-global tuning knobs for experiments and tests (also settable as OVM_TUNE="key=value,..." when the host loads the
+ * library). Defaults are the measured best; none changes results beyond fp32 summation order.
+ *   gemm_bm 0|128|256, gemm_stages 0 (auto: wave-specialised kernel up to 512 tiles, symmetric 2-slot kernel above) |2|3|5|6,
+ *   gemm_splitk 0|1, gemm_tail 0|1 (leftover rows as dot-product workgroups), attn_waves 0 (auto)|4|8, attn_lds_pad bytes,
+ *   attn_tail 0|1, glin_small_max_tiles (-1 = heuristic), glin_target_blocks, glin_max_ksplit, glin_stages 1|2, gbmm_tiled 0|1 */
 int ovm_tune_set(const char* key, int32_t value);
 
 /* --- introspection for tests: copy a named intermediate of the last forward into dst (device).
