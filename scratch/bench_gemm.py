@@ -12,7 +12,7 @@ for (N,K) in ((3072,1024),(1024,1024),(4096,1024),(1024,4096)):
     wi=torch.empty(N,2*K,dtype=torch.float16,device=dev); L.ovm_op_interleave(wh.data_ptr(),wl.data_ptr(),N,K,wi.data_ptr(),None)
     ai=torch.empty(M,2*K,dtype=torch.float16,device=dev); L.ovm_op_interleave(ah.data_ptr(),al.data_ptr(),M,K,ai.data_ptr(),None)
     for prec in (1,3):
-        for bm,st,ail in ((128,2,0),(128,6,0),(128,2,1),(128,6,1)):
+        for bm,st,ail in ((128,2,0),(128,6,0),(256,2,0),(256,3,0)):
             L.ovm_tune_set(b"gemm_bm", bm); L.ovm_tune_set(b"gemm_stages", st)
             if prec==1 and ail: continue
             args=(ah.data_ptr(),al.data_ptr(),K,wh.data_ptr(),wl.data_ptr()) if prec==1 else ((ai.data_ptr(),ai.data_ptr()+64,2*K) if ail else (ah.data_ptr(),al.data_ptr(),K))+(wi.data_ptr(),wi.data_ptr()+64)
