@@ -54,6 +54,23 @@ def test_oracle2d_tiny_vit(device, precision):
     _compare(out, ref)
 
 
+def test_corun_mode_is_scheduling_only(device):
+    """ovm_set_corun (4-wave attention workgroups held to one per CU, for running beside the GroundingDINO stream) must not
+    change results beyond the fp32 summation order of the leftover (cls) query's dot-product path."""
+    cfg = build_cfg("vittest14", 224, "f16x3", max_batch=2)
+    model, sd = _build(cfg)
+    inputs = synth_inputs(2, hw=((140, 196), (224, 168)), n_boxes=12, seed=3)
+    model.backbone.export_features = True
+    base = {k: v.clone() for k, v in model.backbone(model.preprocess_image(inputs)).items()}
+    model.engine.set_corun(True)
+    try:
+        got = model.backbone(model.preprocess_image(inputs))
+        for k in ("p2", "p3", "p4"):
+            assert_close(got[k], base[k], 1e-5, f"corun {k}")
+    finally:
+        model.engine.set_corun(False)
+
+
 def test_oracle2d_vitb_canvas518(device):
     from oracle.pipeline import inference
     cfg = build_cfg("vitb14", 518, "f16x3", max_batch=1)
