@@ -36,8 +36,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   constexpr int PART = 64 * 128;                       // 64 rows x 128 B
   constexpr int SLOT = PART * ((NPASS == 3) ? 2 : 1);  // hi (+ lo)
-  char* const Kring = smem;                            // 2 slots
-  char* const Vring = smem + 2 * SLOT;                 // 2 slots
+  // Ring depth: 2 slots each for K and V^T, or 3 with 8-wave workgroups (one workgroup per CU: 96 KB): the extra slot puts
+  // two key tiles of LDS-DMA in flight, and the end-of-tile wait only covers the tile issued one iteration earlier.
+  constexpr int RD = (NW == 8) ? 3 : 2;
+  char* const Kring = smem;
+  char* const Vring = smem + RD * SLOT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nqb = (p.Tq + 32 * NW - 1) / (32 * NW);
   const int bid = xcd_remap(blockIdx.x, p.main_blocks);
@@ -119,6 +122,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
   stageK(0, 0);
   stageV(0, 0);
   if (nt > 1) stageK(1, 1);
+  if (RD == 3) {
+    if (nt > 2) stageK(2, 2);
+    if (nt > 1) stageV(1, 1);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   f32x16 sc[2], sn[2];
@@ -132,9 +139,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
   auto tile = [&](int it, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
     if (!LAST) {
-      if (it + 2 < nt) stageK(it & 1, it + 2);
-      stageV((it + 1) & 1, it + 1);
-      qk(Kring + ((it + 1) & 1) * SLOT, sn);             // next tile's scores
+      // K(it + RD) goes into the slot of K(it) (scored during the previous iteration), V(it + RD - 1) into that of V(it - 1)
+      if (it + RD < nt) stageK(it % RD, it + RD);
+      if (it + RD - 1 < nt) stageV((it + RD - 1) % RD, it + RD - 1);
+      qk(Kring + ((it + 1) % RD) * SLOT, sn);            // next tile's scores
     }
     const int kbase = it * 64;
     if (LAST) {
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
 #pragma unroll
       for (int e = 0; e < 16; ++e) o0[t][e] *= alpha;
     // ---- O^T += V^T P^T ----
-    const char* vb = Vring + (it & 1) * SLOT;
+    const char* vb = Vring + (it % RD) * SLOT;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int row = 32 * t + r;
@@ -210,8 +218,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
         }
     }
     if (!LAST) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      if (RD == 3) {
+        // the next iteration needs K(it + 2) and V(it + 1), issued one iteration ago; this iteration's own pieces may stay in flight
+        constexpr int PP = PPW * ((NPASS == 3) ? 2 : 1);      // pieces per wave per staged tile
+        const int mine = ((it + RD < nt) ? PP : 0) + ((it + RD - 1 < nt) ? PP : 0);
+        if (mine == 2 * PP) __builtin_amdgcn_s_waitcnt((2 * PP) | (7 << 4) | (15 << 8));
+        else if (mine == PP) __builtin_amdgcn_s_waitcnt(PP | (7 << 4) | (15 << 8));
+        else __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // raw barrier: __syncthreads() would drain vmcnt to 0 again
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
       sc[0] = sn[0];
       sc[1] = sn[1];
     }
@@ -371,7 +390,7 @@ int launch_attention(const AttnParams& p, int npass, hipStream_t s) {
   const dim3 grid(pm.main_blocks + tail_blocks), block(64 * nw);
   const int pad = g_attn_lds_pad > 0 ? g_attn_lds_pad : ((p.corun && nw == 4) ? 40960 : 0);
   if (npass == 3) {
-    const int smem = 2 * 4 * 64 * 128 + pad;
+    const int smem = (nw == 8 ? 3 : 2) * 4 * 64 * 128 + pad;
     if (nw == 8) {
       static bool set8 = false;
       if (!set8) { (void)hipFuncSetAttribute((const void*)attn_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set8 = true; }
@@ -380,7 +399,7 @@ int launch_attention(const AttnParams& p, int npass, hipStream_t s) {
       if (pad > 0) (void)hipFuncSetAttribute((const void*)attn_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
       hipLaunchKernelGGL((attn_kernel<3, 4>), grid, block, smem, s, pm);
     }
-  } else if (nw == 8) hipLaunchKernelGGL((attn_kernel<1, 8>), grid, block, 2 * 2 * 64 * 128, s, pm);
+  } else if (nw == 8) hipLaunchKernelGGL((attn_kernel<1, 8>), grid, block, 3 * 2 * 64 * 128, s, pm);
   else hipLaunchKernelGGL((attn_kernel<1, 4>), grid, block, 2 * 2 * 64 * 128, s, pm);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
