@@ -29,6 +29,9 @@ __device__ __forceinline__ void attn_tail_body(const AttnParams& p, int tb, char
 // overlap without relying on a partner wave. K tiles therefore run one tile ahead of V tiles (two 2-slot
 // LDS rings with a phase offset). Scores are in log2 units (Q is pre-scaled by dh^-0.5 * log2 e), so the
 // probabilities are a bare v_exp_f32.
+#ifndef OVM_ATTN_RD
+#define OVM_ATTN_RD 3      // 4 (three tiles in flight, 128 KB) measured no faster than 3
+#endif
 template <int NPASS, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
   constexpr int SLOT = PART * ((NPASS == 3) ? 2 : 1);  // hi (+ lo)
   // Ring depth: 2 slots each for K and V^T, or 3 with 8-wave workgroups (one workgroup per CU: 96 KB): the extra slot puts
   // two key tiles of LDS-DMA in flight, and the end-of-tile wait only covers the tile issued one iteration earlier.
-  constexpr int RD = (NW == 8) ? 3 : 2;
+  constexpr int RD = (NW == 8) ? OVM_ATTN_RD : 2;
   char* const Kring = smem;
   char* const Vring = smem + RD * SLOT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -122,10 +125,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
   stageK(0, 0);
   stageV(0, 0);
   if (nt > 1) stageK(1, 1);
-  if (RD == 3) {
+  if (RD >= 3) {
     if (nt > 2) stageK(2, 2);
     if (nt > 1) stageV(1, 1);
   }
+  if (RD >= 4) {
+    if (nt > 3) stageK(3, 3);
+    if (nt > 2) stageV(2, 2);
+  }
+  int prev_mine = 0;                                   // pieces this wave issued in the previous iteration (RD = 4)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   f32x16 sc[2], sn[2];
@@ -218,12 +226,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
         }
     }
     if (!LAST) {
-      if (RD == 3) {
-        // the next iteration needs K(it + 2) and V(it + 1), issued one iteration ago; this iteration's own pieces may stay in flight
+      if (RD >= 3) {
+        // the next iteration needs K(it + 2) and V(it + 1), issued RD - 2 iterations ago; what was issued since may stay in flight
         constexpr int PP = PPW * ((NPASS == 3) ? 2 : 1);      // pieces per wave per staged tile
         const int mine = ((it + RD < nt) ? PP : 0) + ((it + RD - 1 < nt) ? PP : 0);
-        if (mine == 2 * PP) __builtin_amdgcn_s_waitcnt((2 * PP) | (7 << 4) | (15 << 8));
-        else if (mine == PP) __builtin_amdgcn_s_waitcnt(PP | (7 << 4) | (15 << 8));
+        const int allow = mine + ((RD >= 4) ? prev_mine : 0);
+        prev_mine = mine;
+        if (allow >= 4 * PP) __builtin_amdgcn_s_waitcnt((4 * PP) | (7 << 4) | (15 << 8));
+        else if (allow == 3 * PP) __builtin_amdgcn_s_waitcnt((3 * PP) | (7 << 4) | (15 << 8));
+        else if (allow == 2 * PP) __builtin_amdgcn_s_waitcnt((2 * PP) | (7 << 4) | (15 << 8));
+        else if (allow == PP) __builtin_amdgcn_s_waitcnt(PP | (7 << 4) | (15 << 8));
         else __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // raw barrier: __syncthreads() would drain vmcnt to 0 again
@@ -390,7 +402,7 @@ int launch_attention(const AttnParams& p, int npass, hipStream_t s) {
   const dim3 grid(pm.main_blocks + tail_blocks), block(64 * nw);
   const int pad = g_attn_lds_pad > 0 ? g_attn_lds_pad : ((p.corun && nw == 4) ? 40960 : 0);
   if (npass == 3) {
-    const int smem = (nw == 8 ? 3 : 2) * 4 * 64 * 128 + pad;
+    const int smem = (nw == 8 ? OVM_ATTN_RD : 2) * 4 * 64 * 128 + pad;
     if (nw == 8) {
       static bool set8 = false;
       if (!set8) { (void)hipFuncSetAttribute((const void*)attn_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set8 = true; }
@@ -399,7 +411,7 @@ int launch_attention(const AttnParams& p, int npass, hipStream_t s) {
       if (pad > 0) (void)hipFuncSetAttribute((const void*)attn_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
       hipLaunchKernelGGL((attn_kernel<3, 4>), grid, block, smem, s, pm);
     }
-  } else if (nw == 8) hipLaunchKernelGGL((attn_kernel<1, 8>), grid, block, 3 * 2 * 64 * 128, s, pm);
+  } else if (nw == 8) hipLaunchKernelGGL((attn_kernel<1, 8>), grid, block, OVM_ATTN_RD * 2 * 64 * 128, s, pm);
   else hipLaunchKernelGGL((attn_kernel<1, 4>), grid, block, 2 * 2 * 64 * 128, s, pm);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
