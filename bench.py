@@ -120,7 +120,8 @@ def main():
 
     def run(precision, steps, warmup, profile):
         cfg = build_cfg(args.model, args.canvas, precision, max_batch=B, max_rois=1000 if use_gdino else max(64, args.boxes),
-                        roi_heads="ROIHeads3DGDINO" if use_gdino else "ROIHeads3D")
+                        roi_heads="ROIHeads3DGDINO" if use_gdino else "ROIHeads3D",
+                        extra=["MODEL.AMD.GDINO_CORUN", os.environ.get("OVM_BENCH_CORUN", "0") == "1"])
         model = build_model(cfg, device=dev)
         model.load_state_dict(sd)
         if use_gdino:

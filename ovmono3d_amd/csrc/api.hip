@@ -705,8 +705,8 @@ int ovm_rpn_box_forward(OvmHandle* h, const OvmImage* images, int32_t B, float* 
 }
 
 // Co-run mode: the caller runs other work (the GroundingDINO detector) on a second stream while ovm_backbone_forward executes. The
-// attention launches then keep to one 4-wave workgroup per CU (slower alone: 6.7 -> 9.5 ms per ViT-L image) so that the other stream's
-// short kernels find free wave slots instead of queueing behind 290-us workgroups; measured end to end 28.6 -> 27.0 ms per image.
+// attention launches then keep to one 4-wave workgroup per CU (slower alone: 6.8 -> 9.3 ms per ViT-L image) so that the other stream's
+// short kernels find free wave slots instead of queueing behind 270-us workgroups; measured end to end 28.3 -> 26.7 ms per image.
 int ovm_set_corun(OvmHandle* h, int32_t on) {
   if (!h) return OVM_ERR_INVALID;
   h->corun = on != 0;

@@ -39,9 +39,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   constexpr int PART = 64 * 128;                       // 64 rows x 128 B
   constexpr int SLOT = PART * ((NPASS == 3) ? 2 : 1);  // hi (+ lo)
-  // Ring depth: 2 slots each for K and V^T, or 3 with 8-wave workgroups (one workgroup per CU: 96 KB): the extra slot puts
-  // two key tiles of LDS-DMA in flight, and the end-of-tile wait only covers the tile issued one iteration earlier.
-  constexpr int RD = (NW == 8) ? OVM_ATTN_RD : 2;
+  // Ring depth 3 for K and for V^T (96 KB: one workgroup per CU): two key tiles of LDS-DMA stay in flight and the end-of-tile
+  // wait only covers the tile issued one iteration earlier.
+  constexpr int RD = OVM_ATTN_RD;
   char* const Kring = smem;
   char* const Vring = smem + RD * SLOT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -385,8 +385,8 @@ int launch_attention(const AttnParams& p, int npass, hipStream_t s) {
   AttnParams pm = p;
   // Default: 8-wave workgroups - 256 queries share one K / V^T tile stream, i.e. half the LDS-DMA traffic of two 4-wave
   // workgroups per CU at the same 2 waves per SIMD (7.6 -> 6.7 ms per ViT-L image). Co-run mode (another stream's short kernels
-  // run beside this launch): ONE 4-wave workgroup per CU, held there by 40 KB of unused LDS; that kernel is slower by itself
-  // (9.5 ms) but leaves half of the wave slots free, which shortens the other stream's chain by more than it costs
+  // run beside this launch): ONE 4-wave workgroup per CU; that kernel is slower by itself
+  // (~9 ms) but leaves half of the wave slots free, which shortens the other stream's chain by more than it costs
   // (28.6 -> 27.5 ms per image end to end; 8 waves per CU in either arrangement do not).
   const int nw = g_attn_waves ? g_attn_waves : (p.corun ? 4 : 8);
   const int qpb = 32 * nw;
@@ -400,19 +400,20 @@ int launch_attention(const AttnParams& p, int npass, hipStream_t s) {
   const int nqb = (pm.Tq + qpb - 1) / qpb;
   pm.main_blocks = nqb * p.heads * p.B;
   const dim3 grid(pm.main_blocks + tail_blocks), block(64 * nw);
-  const int pad = g_attn_lds_pad > 0 ? g_attn_lds_pad : ((p.corun && nw == 4) ? 40960 : 0);
+  const int pad = g_attn_lds_pad;                  // experiment knob; the 3-slot rings (96 KB) already keep a workgroup alone on its CU
   if (npass == 3) {
-    const int smem = (nw == 8 ? OVM_ATTN_RD : 2) * 4 * 64 * 128 + pad;
+    const int smem = OVM_ATTN_RD * 4 * 64 * 128 + pad;
     if (nw == 8) {
       static bool set8 = false;
       if (!set8) { (void)hipFuncSetAttribute((const void*)attn_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set8 = true; }
       hipLaunchKernelGGL((attn_kernel<3, 8>), grid, block, smem, s, pm);
     } else {
-      if (pad > 0) (void)hipFuncSetAttribute((const void*)attn_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      static bool set4 = false;
+      if (!set4 || pad > 0) { (void)hipFuncSetAttribute((const void*)attn_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set4 = true; }
       hipLaunchKernelGGL((attn_kernel<3, 4>), grid, block, smem, s, pm);
     }
   } else if (nw == 8) hipLaunchKernelGGL((attn_kernel<1, 8>), grid, block, OVM_ATTN_RD * 2 * 64 * 128, s, pm);
-  else hipLaunchKernelGGL((attn_kernel<1, 4>), grid, block, 2 * 2 * 64 * 128, s, pm);
+  else hipLaunchKernelGGL((attn_kernel<1, 4>), grid, block, OVM_ATTN_RD * 2 * 64 * 128, s, pm);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 
