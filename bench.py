@@ -121,7 +121,7 @@ def main():
     def run(precision, steps, warmup, profile):
         cfg = build_cfg(args.model, args.canvas, precision, max_batch=B, max_rois=1000 if use_gdino else max(64, args.boxes),
                         roi_heads="ROIHeads3DGDINO" if use_gdino else "ROIHeads3D",
-                        extra=["MODEL.AMD.GDINO_CORUN", os.environ.get("OVM_BENCH_CORUN", "1") == "1"])
+                        extra=["MODEL.AMD.GDINO_CORUN", os.environ.get("OVM_BENCH_CORUN", "0") == "1"])
         model = build_model(cfg, device=dev)
         model.load_state_dict(sd)
         if use_gdino:
@@ -199,9 +199,8 @@ def main():
                 "algorithmic_flops_per_launch": flops_launch,
                 "mfma_passes_per_product": 3 if args.precision == "f16x3" else 1}
     if use_gdino:
-        roofline["note"] = ("launch durations are measured while the GroundingDINO graph runs concurrently on a side stream and, in co-run "
-                            "mode (MODEL.AMD.GDINO_CORUN, default on), with the attention deliberately run as one 4-wave workgroup per CU: "
-                            "a slower kernel for a faster step; --proposals oracle2d gives the uncontended 8-wave figure")
+        roofline["note"] = ("launch durations are measured while the GroundingDINO graph runs concurrently on a side stream "
+                            "(the kernels share the CUs); --proposals oracle2d gives the uncontended figure")
     kernels = {k: {"ms_per_step": round(prof[k][0] / args.steps, 4), "launches_per_step": prof[k][1] // args.steps,
                    **({"tflops": round(kf[k] * B * prof[k][1] / (prof[k][0] * 1e-3) / 1e12, 2)} if k in kf and prof[k][0] > 0 else {})}
                for k in prof}

@@ -264,8 +264,8 @@ def get_cfg_defaults(cfg: CfgNode) -> CfgNode:
                                  GDINO_WEIGHTS="./checkpoints/groundingdino_swinb_cogcoor.pth", BERT_VOCAB="",
                                  GDINO_OVERLAP=True, GDINO_GRAPHS=True,
                                  # co-run mode: throttle the ViT attention to one 4-wave workgroup per CU while the detector runs beside it
-                                 # (+6 % images/s end to end; the attention kernel itself runs 1.4x slower while it shares the chip)
-                                 GDINO_CORUN=True,
+                                 # (0 to +6 % images/s end to end depending on the box; the attention kernel itself runs 1.4x slower: off by default)
+                                 GDINO_CORUN=False,
                                  # ResizeShortestEdge on the device (bit-identical to the host's Pillow resize)
                                  GPU_RESIZE=True))
     return cfg

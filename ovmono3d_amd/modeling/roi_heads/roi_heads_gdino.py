@@ -66,7 +66,7 @@ class ROIHeads3DGDINO(ROIHeads3D):
         if not category_list or len(images.image_sizes) != 1 or not bool(self._gdino_cfg.MODEL.AMD.GDINO_OVERLAP):
             self.engine.set_corun(False)
             return
-        self.engine.set_corun(bool(self._gdino_cfg.MODEL.AMD.get("GDINO_CORUN", True)))   # optional: attention leaves room for the detector
+        self.engine.set_corun(bool(self._gdino_cfg.MODEL.AMD.get("GDINO_CORUN", False)))   # optional: attention leaves room for the detector
         if self.detector is None:
             self.load_detector()
         from .gdino_glue import build_caption
