@@ -3,8 +3,8 @@
 //   softmax(q k^T) v with q pre-scaled by dh^-0.5 * log2(e) in the QKV epilogue (probabilities = exp2) (dinov2 Attention.forward as the
 //   reference reaches it at dino.py:89-90; the xFormers path of nohup.out:696-701 computes the same).
 //
-// Work split: one workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries.
-// K and V^T tiles of 64 keys arrive by global_load_lds (two LDS stages, source-side swizzle).
+// Work split: one workgroup = NW waves (8 by default, 4 in co-run mode) = 32 NW queries of one (batch, head); each wave owns 32
+// queries. K and V^T tiles of 64 keys arrive by global_load_lds (3-slot rings shared by the workgroup, source-side swizzle).
 // Orientation ("key on the MFMA row"): S^T = K Q^T with v_mfma_f32_32x32x16_f16, so a lane holds one
 // query column and 32 of the 64 keys in registers - softmax needs one cross-half shuffle per tile and
 // the S^T accumulator is directly the B operand of O^T = V^T P^T (no LDS round trip for P).
@@ -26,7 +26,7 @@ __device__ __forceinline__ void attn_tail_body(const AttnParams& p, int tb, char
 
 // Software-pipelined over key tiles inside each wave: iteration t issues the S^T MFMAs of tile t+1, the
 // softmax VALU work of tile t and the PV MFMAs of tile t as one basic block, so matrix and vector pipes
-// overlap without relying on a partner wave. K tiles therefore run one tile ahead of V tiles (two 2-slot
+// overlap without relying on a partner wave. K tiles therefore run one tile ahead of V tiles (two
 // LDS rings with a phase offset). Scores are in log2 units (Q is pre-scaled by dh^-0.5 * log2 e), so the
 // probabilities are a bare v_exp_f32.
 #ifndef OVM_ATTN_RD
