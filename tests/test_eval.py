@@ -78,6 +78,20 @@ def test_depth_range_assignment():
     assert abs(s["AP"] - 100.0 * 67 / 101) < 1e-9                           # recall reaches 2/3: points 0 .. 0.66
 
 
+def test_omni3d_json_to_gt_fields_and_ignore_flags():
+    from ovmono3d_amd.evaluation.omni3d_eval import omni3d_json_to_gt
+    c3 = ob.make_box([0, 0, 5], [1, 1, 1], np.eye(3)).tolist()
+    js = {"annotations": [
+        {"image_id": 1, "category_id": 4, "bbox2D_proj": [10, 20, 60, 80], "bbox3D_cam": c3, "center_cam": [0, 0, 5.0], "behind_camera": False},
+        {"image_id": 1, "category_id": 4, "bbox2D_proj": [-1, -1, -1, -1], "bbox2D_tight": [5, 5, 25, 45], "bbox3D_cam": c3, "center_cam": [0, 0, 7.0],
+         "behind_camera": True},
+        {"image_id": 2, "category_id": 9, "bbox2D_proj": [-1, -1, -1, -1], "bbox2D_tight": [-1, -1, -1, -1], "bbox2D_trunc": [-1, -1, -1, -1]}]}
+    g = omni3d_json_to_gt(js)
+    assert g[0]["bbox"] == [10.0, 20.0, 50.0, 60.0] and g[0]["depth"] == 5.0 and g[0]["ignore2D"] == 0 and g[0]["ignore3D"] == 0
+    assert g[1]["bbox"] == [5.0, 5.0, 20.0, 40.0] and g[1]["ignore3D"] == 1 and g[1]["ignore2D"] == 0      # falls back to the tight box; behind the camera
+    assert g[2]["ignore2D"] == 1 and g[2]["ignore3D"] == 1 and np.asarray(g[2]["bbox3D"]).shape == (8, 3)
+
+
 # ---------------------------------------------------------------- GPU: the HIP kernel -----------------------------------------
 @pytest.mark.gpu
 def test_box3d_iou_kernel_matches_exact_oracle(device):
