@@ -6,10 +6,11 @@ first image's focal length sticks) -> ResizeShortestEd
 width, K, category_list}]) -> threshold on score (:99). Drawing (vis.draw_scene_view, :107-118) is
 presentation and out of scope: detections are written as JSON next to where the reference writes its JPEGs.
 
-2D boxes: the reference's demo always goes through ROIHeads3DGDINO (category_list is set, :84). The native
-GroundingDINO network is not built yet, so either attach a detector, or pass ``--boxes-file`` with
-oracle-2D boxes ({image name: [{bbox xywh, category_id, score}]}), or select ``MODEL.ROI_HEADS.NAME
-ROIHeads3D`` to run the RPN + box-head path.
+2D boxes: the reference's demo always goes through ROIHeads3DGDINO (category_list is set, :84). Select it with
+``MODEL.ROI_HEADS.NAME ROIHeads3DGDINO``: the native GroundingDINO network (``ovmono3d_amd/gdino``) is built from
+``MODEL.AMD.GDINO_WEIGHTS`` (+ ``MODEL.AMD.BERT_VOCAB``) on first use and raises if the checkpoint is missing. Alternatives:
+``--boxes-file`` with oracle-2D boxes ({image name: [{bbox xywh, category_id, score}]}), or the default
+``MODEL.ROI_HEADS.NAME ROIHeads3D`` = the RPN + box-head path.
 """
 import argparse
 import json

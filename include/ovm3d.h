@@ -138,6 +138,10 @@ int ovm_rpn_box_forward(OvmHandle* h, const OvmImage* images, int32_t B, float* 
 int ovm_gather_records(void* comm, int32_t rank, int32_t world, const OvmDet3D* send, int32_t n_send,
                        OvmDet3D* recv, int32_t* counts_all, ovm_stream_t stream);
 
+/* The counts exchange alone, so that rank 0 can size `recv` first: every rank calls it, then every rank calls
+ * ovm_gather_records (which repeats the 4-byte exchange). counts_all: host, world ints, filled on every rank. */
+int ovm_gather_counts(void* comm, int32_t rank, int32_t world, int32_t n_send, int32_t* counts_all, ovm_stream_t stream);
+
 int ovm_comm_unique_id(uint8_t* id128);                                     /* ncclGetUniqueId */
 int ovm_comm_init(const uint8_t* id128, int32_t rank, int32_t world, int32_t device, void** comm);
 int ovm_comm_destroy(void* comm);

@@ -200,7 +200,24 @@ def get_cfg_defaults(cfg: CfgNode) -> CfgNode:
     cfg.DATASETS.CATEGORY_NAMES_BASE = ("bicycle", "books", "bottle", "camera", "cereal box",
                                         "chair", "cup", "laptop", "shoes")
     cfg.DATASETS.CATEGORY_NAMES_NOVEL = ()
-    cfg.DATASETS.ORACLE2D_FILES = CfgNode(dict(EVAL_MODE="target_aware"))
+    # Oracle-2D files per evaluation mode and split (reference config.py:42-76). The reference hard-codes absolute paths on the
+    # author's cluster (:71,:76); here they are relative to the Omni3D folder ("datasets/Omni3D", README.md:70-74) with the same
+    # file names, and tools/train_net.py also looks for the base name under --datasets-root. The fork leaves only Objectron_test
+    # active (:62); the upstream lists it comments out are kept so that TEST.CAT_MODE novel + target_aware finds its files.
+    o2d = CfgNode(dict(EVAL_MODE="target_aware"))                      # 'target_aware' or 'previous_metric'
+    novel_datasets = {"SUNRGBD_test_novel": "sunrgbd", "ARKitScenes_test_novel": "arkitscenes", "KITTI_test_novel": "kitti"}
+    base_datasets = {"SUNRGBD_test": "sunrgbd", "Hypersim_test": "hypersim", "ARKitScenes_test": "arkitscenes",
+                     "Objectron_test": "objectron", "KITTI_test": "kitti", "nuScenes_test": "nuscenes"}
+    for mode in ("target_aware", "previous_metric"):
+        node = CfgNode(dict(novel=CfgNode(), base=CfgNode()))
+        for dataset, short in novel_datasets.items():
+            prefix = "gdino_novel_previous_metric" if mode == "previous_metric" else "gdino"
+            node.novel[dataset] = f"datasets/Omni3D/{prefix}_{short}_novel_oracle_2d.json"
+        for dataset, short in base_datasets.items():
+            prefix = "gdino_previous_eval" if mode == "previous_metric" else "gdino"
+            node.base[dataset] = f"datasets/Omni3D/{prefix}_{short}_base_oracle_2d.json"
+        o2d[mode] = node
+    cfg.DATASETS.ORACLE2D_FILES = o2d
 
     cfg.MODEL.FPN.IN_FEATURE = None
     cfg.MODEL.FPN.SQUARE_PAD = 0

@@ -775,6 +775,22 @@ int64_t ovm_debug_copy(OvmHandle* h, const char* name, float* dst, int64_t capac
   return n;
 }
 
+// Counts exchange alone (every rank calls it): lets rank 0 size its receive buffer before ovm_gather_records.
+int ovm_gather_counts(void* comm, int32_t rank, int32_t world, int32_t n_send, int32_t* counts_all, ovm_stream_t stream) {
+  if (!comm || world < 1 || rank < 0 || rank >= world || !counts_all || n_send < 0) return OVM_ERR_INVALID;
+  ncclComm_t cm = (ncclComm_t)comm;
+  hipStream_t s = (hipStream_t)stream;
+  int* d_counts = nullptr;
+  if (hipMalloc((void**)&d_counts, sizeof(int) * (world + 1)) != hipSuccess) return OVM_ERR_HIP;
+  int rc = OVM_OK;
+  if (hipMemcpyAsync(d_counts + world, &n_send, sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) rc = OVM_ERR_HIP;
+  else if (ncclAllGather(d_counts + world, d_counts, 1, ncclInt32, cm, s) != ncclSuccess) rc = OVM_ERR_HIP;
+  else if (hipMemcpyAsync(counts_all, d_counts, sizeof(int) * world, hipMemcpyDeviceToHost, s) != hipSuccess) rc = OVM_ERR_HIP;
+  if (hipStreamSynchronize(s) != hipSuccess) rc = OVM_ERR_HIP;
+  hipFree(d_counts);
+  return rc;
+}
+
 // One gather of fixed-width records to rank 0: counts all-gather, then grouped send/recv (a gatherv).
 // Every peer uses its own xGMI link to rank 0's GPU; the payload is ~200 B per detection.
 int ovm_gather_records(void* comm, int32_t rank, int32_t world, const OvmDet3D* send, int32_t n_send, OvmDet3D* recv,

@@ -273,12 +273,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
 
 // ---------------------------------------------------------------------------------------------
 // Tail query rows. T = 4097 leaves ONE query past 32 blocks of 128; as a 33rd block per head it would
-// add a second, nearly empty round of workgroups. Up to 8 leftover queries per (batch, head) are handled
-// here instead: one workgroup per (query, batch*head), scores and probabilities in LDS, fp32 FMAs on the
-// reconstructed (hi + lo) operands.
-// ---------------------------------------------------------------------------------------------
-// ---------------------------------------------------------------------------------------------
-// Tail query rows. T = 4097 leaves ONE query past 32 blocks of 128; as a 33rd block per head it would
 // add a second, nearly empty round of workgroups. Up to 8 leftover queries per (batch, head) are handled by
 // extra workgroups of the same launch instead: scores and probabilities in LDS, fp32 FMAs on the
 // reconstructed (hi + lo) operands, all global reads coalesced along the contiguous axis.
@@ -375,7 +369,7 @@ static int g_attn_tail = 1;
 void attn_set_tail_rows(int on) { g_attn_tail = on; }
 static int g_attn_lds_pad = 0;      // experiment: extra dynamic LDS per workgroup (lowers workgroups per CU)
 void attn_set_lds_pad(int v) { g_attn_lds_pad = v; }
-static int g_attn_waves = 0;        // 0 = automatic (8 in co-run mode, else 4)
+static int g_attn_waves = 0;        // 0 = automatic (8 by default, 4 in co-run mode)
 void attn_set_waves(int v) { g_attn_waves = (v == 4 || v == 8) ? v : 0; }
 
 int launch_attention(const AttnParams& p, int npass, hipStream_t s) {

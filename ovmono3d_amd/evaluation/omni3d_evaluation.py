@@ -61,24 +61,24 @@ class Omni3DEvaluator:
         return instances_to_coco_json(instances, img_id)
 
 
-def _records_of(instances, image_index: int) -> torch.Tensor:
-    """[n,48] float32 record tensor of one image's Instances (layout OvmDet3D)."""
+def _records_of(instances, image_index: int, device: torch.device) -> torch.Tensor:
+    """[n,48] float32 record tensor of one image's Instances (layout OvmDet3D) on ``device`` - the device the run gathers
+    on, NOT the device of the instance fields: an image with no detection (empty oracle list, no GroundingDINO box, the
+    n == 0 early return of ``_forward_cube``) carries CPU or no fields and must still concatenate with its neighbours."""
     n = len(instances) if instances.get_fields() else 0
-    dev = instances.scores.device if n else torch.device("cpu")
-    rec = torch.zeros((n, 48), dtype=torch.float32, device=dev)
+    rec = torch.zeros((n, 48), dtype=torch.float32, device=device)
     if n == 0:
         return rec
-    rec[:, 0:4] = instances.pred_boxes.tensor
-    rec[:, 4] = instances.scores
-    rec[:, 5] = instances.pred_classes.to(torch.int32).view(torch.float32) if instances.pred_classes.dtype == torch.int32 \
-        else instances.pred_classes.to(torch.int32).contiguous().view(torch.float32)
+    rec[:, 0:4] = instances.pred_boxes.tensor.to(device)
+    rec[:, 4] = instances.scores.to(device)
+    rec[:, 5] = instances.pred_classes.to(device, torch.int32).contiguous().view(torch.float32)
     if instances.has("pred_bbox3D"):
-        rec[:, 6:30] = instances.pred_bbox3D.reshape(n, 24)
-        rec[:, 30:33] = instances.pred_center_cam
-        rec[:, 33:35] = instances.pred_center_2D
-        rec[:, 35:38] = instances.pred_dimensions
-        rec[:, 38:47] = instances.pred_pose.reshape(n, 9)
-    rec[:, 47] = torch.full((n,), image_index, dtype=torch.int32, device=dev).view(torch.float32)
+        rec[:, 6:30] = instances.pred_bbox3D.reshape(n, 24).to(device)
+        rec[:, 30:33] = instances.pred_center_cam.to(device)
+        rec[:, 33:35] = instances.pred_center_2D.to(device)
+        rec[:, 35:38] = instances.pred_dimensions.to(device)
+        rec[:, 38:47] = instances.pred_pose.reshape(n, 9).to(device)
+    rec[:, 47] = torch.full((n,), image_index, dtype=torch.int32, device=device).view(torch.float32)
     return rec
 
 
@@ -106,6 +106,9 @@ def inference_on_dataset(model, data_loader, evaluator=None) -> List[Dict]:
     metas: List[Dict] = []
     recs: List[torch.Tensor] = []
     n_img = 0
+    # records live on the model's device (with world > 1 the nccl gather needs device tensors on every rank, also on a rank
+    # whose images all came back empty)
+    rec_dev = torch.device(getattr(model, "device", None) or "cpu")
     model.eval()
     with torch.no_grad():
         start_data = time.perf_counter()
@@ -128,7 +131,7 @@ def inference_on_dataset(model, data_loader, evaluator=None) -> List[Dict]:
                 inst = out["instances"]
                 metas.append({"image_id": inp.get("image_id", inp.get("file_name", str(idx))), "K": inp["K"],
                               "width": inp["width"], "height": inp["height"], "n": len(inst) if inst.get_fields() else 0})
-                recs.append(_records_of(inst, n_img))
+                recs.append(_records_of(inst, n_img, rec_dev))
                 n_img += 1
             total_eval += time.perf_counter() - t0
             iters = idx + 1 - num_warmup * int(idx >= num_warmup)
@@ -145,8 +148,7 @@ def inference_on_dataset(model, data_loader, evaluator=None) -> List[Dict]:
                 f"on {world} devices)")
     logger.info(f"Total inference pure compute time: {datetime.timedelta(seconds=int(total_compute))} "
                 f"({total_compute / denom:.6f} s / iter per device, on {world} devices)")
-    dev = recs[0].device if recs else torch.device("cpu")
-    mine = torch.cat(recs) if recs else torch.zeros((0, 48), dtype=torch.float32, device=dev)
+    mine = torch.cat(recs) if recs else torch.zeros((0, 48), dtype=torch.float32, device=rec_dev)
     if world > 1:
         import torch.distributed as dist
         allrec, _ = gather_records(mine, dst=0)                                        # :717-720, one gather per dataset

@@ -46,7 +46,7 @@ class OvmImage(C.Structure):
 
 EXPORTS = [
     "ovm_create", "ovm_destroy", "ovm_last_error", "ovm_version", "ovm_backbone_forward", "ovm_cube_forward",
-    "ovm_rpn_box_forward", "ovm_gather_records", "ovm_host_interp_pos_embed", "ovm_host_shard_range",
+    "ovm_rpn_box_forward", "ovm_gather_records", "ovm_gather_counts", "ovm_host_interp_pos_embed", "ovm_host_shard_range",
     "ovm_op_split_f16", "ovm_op_interleave", "ovm_op_gemm", "ovm_op_layernorm", "ovm_op_attention", "ovm_op_roi_align",
     "ovm_op_cube_decode", "ovm_op_nms", "ovm_debug_copy", "ovm_set_corun", "ovm_profile_enable", "ovm_profile_read",
     "ovm_comm_unique_id", "ovm_comm_init", "ovm_comm_destroy", "ovm_tune_set", "ovm_gdino_postprocess", "ovm_box3d_iou", "ovm_host_pil_bilinear_coeffs", "ovm_resize_bilinear_u8",
@@ -78,6 +78,7 @@ def load() -> C.CDLL:
     lib.ovm_cube_forward.argtypes = [vp, C.POINTER(OvmImage), i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     lib.ovm_rpn_box_forward.argtypes = [vp, C.POINTER(OvmImage), i32, vp, vp, vp, vp, vp, vp, vp]
     lib.ovm_gather_records.argtypes = [vp, i32, i32, vp, i32, vp, C.POINTER(i32), vp]
+    lib.ovm_gather_counts.argtypes = [vp, i32, i32, i32, C.POINTER(i32), vp]
     lib.ovm_host_interp_pos_embed.argtypes = [vp, i32, i32, i32, vp]
     lib.ovm_host_shard_range.argtypes = [i64, i32, i32, C.POINTER(i64), C.POINTER(i64)]
     lib.ovm_op_split_f16.argtypes = [vp, i64, vp, vp, vp]

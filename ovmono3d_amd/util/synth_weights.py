@@ -25,6 +25,9 @@ VIT_ARCH = {
     "vitg14": (1536, 40, 24),
     # tiny architecture for fast CPU tests (not a hub model)
     "vittest14": (128, 2, 2),
+    # ViT-L width at depth 2: full-size token / channel geometry (T = 4097 or 5477, D = 1024, 16 heads) at a cost the CPU
+    # oracle finishes in seconds (not a hub model)
+    "vitl14_d2": (1024, 2, 16),
 }
 
 

@@ -42,7 +42,7 @@ def test_records_json_equals_instances_to_coco_json():
     from ovmono3d_amd.evaluation.omni3d_evaluation import _json_of_records, _records_of, instances_to_coco_json
     inst = _fake_instances(5, 1)
     a = instances_to_coco_json(inst, 42)
-    b = _json_of_records(_records_of(inst, 0), 42)
+    b = _json_of_records(_records_of(inst, 0, torch.device("cpu")), 42)
     assert len(a) == len(b) == 5
     for x, y in zip(a, b):
         assert x["image_id"] == y["image_id"] == 42 and x["category_id"] == y["category_id"]
@@ -62,6 +62,18 @@ class _StubModel:
         return [{"instances": _fake_instances(int(x["image_id"]) % 3, int(x["image_id"]))} for x in inputs]
 
 
+class _EmptyFieldsModel(_StubModel):
+    """image_id % 3 == 0 -> an Instances with NO fields at all (the n == 0 early return of _forward_cube for a
+    GroundingDINO image without boxes); the others as _StubModel."""
+
+    def __call__(self, inputs, prompt_depth=None):
+        out = []
+        for x in inputs:
+            n = int(x["image_id"]) % 3
+            out.append({"instances": _fake_instances(n, int(x["image_id"])) if n else Instances((10, 10))})
+        return out
+
+
 class _Loader(list):
     pass
 
@@ -78,6 +90,14 @@ def test_inference_on_dataset_single_process():
     assert [r["image_id"] for r in res] == list(range(7))
     assert [len(r["instances"]) for r in res] == [i % 3 for i in range(7)]
     assert set(res[2]["instances"][0]) >= {"image_id", "category_id", "bbox", "score", "bbox3D", "center_cam", "depth"}
+
+
+def test_inference_on_dataset_empty_images_between_nonempty():
+    """reference omni3d_evaluation.py:717-720: images without detections still occupy their slot in dataset order."""
+    from ovmono3d_amd.evaluation import inference_on_dataset
+    res = inference_on_dataset(_EmptyFieldsModel(), _make_loader(7, 0, 1))
+    assert [len(r["instances"]) for r in res] == [i % 3 for i in range(7)]
+    assert res[3]["instances"] == [] and res[4]["image_id"] == 4
 
 
 def _free_port():
@@ -119,6 +139,38 @@ def test_inference_on_dataset_two_ranks_gloo():
     assert got == exp
 
 
+class _OnlyFirstShardModel(_StubModel):
+    """detections only for image ids < 2: with 4 images on 2 ranks the second rank gathers zero records."""
+
+    def __call__(self, inputs, prompt_depth=None):
+        return [{"instances": _fake_instances(2, int(x["image_id"])) if int(x["image_id"]) < 2 else Instances((10, 10))} for x in inputs]
+
+
+def _worker_empty_rank(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ovmono3d_amd.evaluation import inference_on_dataset
+    res = inference_on_dataset(_OnlyFirstShardModel(), _make_loader(4, rank, world))
+    if rank == 0:
+        q.put(json.dumps([[r["image_id"], len(r["instances"])] for r in res]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_inference_on_dataset_two_ranks_one_rank_all_empty():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker_empty_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = json.loads(q.get(timeout=120))
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got == [[0, 2], [1, 2], [2, 0], [3, 0]]
+
+
 def test_synthetic_checkpoint_uri_and_key_tree():
     """DetectionCheckpointer accepts synthetic://<arch>?seed=N; keys follow the reference module tree (nohup.out:563-684)."""
     from ovmono3d_amd.util.synth_weights import synth_state_dict
@@ -130,3 +182,22 @@ def test_synthetic_checkpoint_uri_and_key_tree():
         assert k in sd, k
     assert sd["backbone.simfp_2.0.weight"].shape == (128, 64, 2, 2)
     assert sd["roi_heads.cube_head.feature_generator.fc1.weight"].shape == (1024, 12544)
+
+
+def test_oracle2d_file_defaults_resolve(tmp_path):
+    """DATASETS.ORACLE2D_FILES carries root-relative defaults with the reference's file names (config.py:42-76) and
+    tools/train_net.py finds them under --datasets-root for TEST.CAT_MODE novel + target_aware (BASELINE config 3)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ovm_train_net", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "train_net.py"))
+    tn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tn)
+    cfg = build_cfg()
+    assert cfg.DATASETS.ORACLE2D_FILES.EVAL_MODE == "target_aware"
+    assert tn.oracle2d_file(cfg, "novel", "KITTI_test_novel", str(tmp_path)) is None
+    f = tmp_path / "gdino_kitti_novel_oracle_2d.json"
+    f.write_text("[]")
+    assert tn.oracle2d_file(cfg, "novel", "KITTI_test_novel", str(tmp_path)) == str(f)
+    assert tn.oracle2d_file(cfg, "base", "Objectron_test", str(tmp_path)) is None
+    (tmp_path / "gdino_objectron_base_oracle_2d.json").write_text("[]")
+    assert tn.oracle2d_file(cfg, "base", "Objectron_test", str(tmp_path)).endswith("gdino_objectron_base_oracle_2d.json")
+    assert tn.oracle2d_file(cfg, "base", "NoSuch_test", str(tmp_path)) is None

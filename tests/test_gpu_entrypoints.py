@@ -127,3 +127,24 @@ def test_oracle2d_producer_roundtrip(device, tmp_path):
     o = dicts[0]["oracle2D"]
     assert o["gt_bbox2D"].shape[1] == 4 and len(o["gt_classes"]) == len(o["gt_scores"]) == o["gt_bbox2D"].shape[0]
     assert torch.isfinite(o["gt_bbox2D"]).all()              # not clipped to the image: the reference's GroundingDINO glue does not clip either
+
+
+def test_rccl_gather_c_abi_one_rank(device):
+    """ovm_comm_unique_id / ovm_comm_init / ovm_gather_counts / ovm_gather_records on a one-rank RCCL communicator (the N > 1
+    exchange needs N GPUs; this exercises the C ABI, the counts exchange and the payload path so that the first 8-GPU run is
+    not also its first execution), and the routing of evaluation.distributed.gather_records through it.
+    Replaces comm.gather(dst=0) of reference omni3d_evaluation.py:717-720."""
+    from ovmono3d_amd.evaluation import distributed as D
+    comm = D.NativeComm(D.NativeComm.new_unique_id(), 0, 1, device)
+    try:
+        rec = torch.arange(5 * 48, dtype=torch.float32, device=device).view(5, 48)
+        out, counts = comm.gather(rec)
+        assert counts == [5] and torch.equal(out, rec) and out.data_ptr() != rec.data_ptr()
+        out0, counts0 = comm.gather(rec[:0])                                  # a rank without detections
+        assert counts0 == [0] and out0.shape == (0, 48)
+        D.set_native_comm(comm)
+        out2, counts2 = D.gather_records(rec)
+        assert counts2 == [5] and torch.equal(out2, rec) and out2.data_ptr() != rec.data_ptr()
+    finally:
+        D.set_native_comm(None)
+        comm.close()

@@ -197,25 +197,7 @@ def _small_hf_gdino():
     return hf, cfg
 
 
-def _patch_hf_to_upstream(hf):
-    # transformers 5.x's BertModel adds a 4-D bool mask as +1.0 (no masking); upstream GroundingDINO builds the additive
-    # mask (get_extended_attention_mask). Feed HF what upstream computes.
-    tb = hf.model.text_backbone
-    orig = tb.forward
-
-    def patched(input_ids, attention_mask=None, token_type_ids=None, position_ids=None, **kw):
-        if attention_mask is not None and attention_mask.dtype == torch.bool:
-            attention_mask = torch.where(attention_mask, 0.0, torch.finfo(torch.float32).min)
-        return orig(input_ids, attention_mask, token_type_ids, position_ids, **kw)
-    tb.forward = patched
-    # transformers 5.x's encode_sinusoidal_position_embedding casts its result back to the input dtype; the encoder layers call it
-    # with int64 text position ids, which truncates the text position embedding to integers. Upstream (get_sine_pos_embed) keeps
-    # floats; make HF do the same.
-    import transformers.models.grounding_dino.modeling_grounding_dino as mgd
-    if not getattr(mgd, "_ovm_patched", False):
-        orig_enc = mgd.encode_sinusoidal_position_embedding
-        mgd.encode_sinusoidal_position_embedding = lambda pos, **kw: orig_enc(pos.float(), **kw)
-        mgd._ovm_patched = True
+from hf_gdino_patches import patch_hf_to_upstream as _patch_hf_to_upstream, upstream_position_ids  # noqa: E402
 
 
 def test_full_gdino_network_matches_hf(device):
@@ -322,7 +304,6 @@ def test_roiheads3dgdino_end_to_end_vs_hf_and_oracle(device):
     """The whole text-prompted path (SURVEY.md 8a row a10 + a11-a14) against independent code: native model with
     ROIHeads3DGDINO  vs  [HF GroundingDINO (CPU) -> oracle glue -> oracle cube head / decode / postprocess] on the same image,
     caption and weights. Same detections (count, order, class ids), float fields within 1e-3."""
-    import transformers.models.grounding_dino.modeling_grounding_dino as mgd
     from common import build_cfg, oracle_params, synth_inputs
     from oracle import gdino_glue as og
     from oracle.pipeline import inference
@@ -350,20 +331,15 @@ def test_roiheads3dgdino_end_to_end_vs_hf_and_oracle(device):
 
     # independent route. HF numbers the text positions its own way (delimiters get 0); upstream - which the native path
     # follows - numbers them 0..len inside each phrase: give HF upstream's ids for this comparison
-    orig = mgd.generate_masks_with_special_tokens_and_transfer_map
-    mgd.generate_masks_with_special_tokens_and_transfer_map = lambda ids: (orig(ids)[0], masks_and_position_ids(ids[0])[1][None].to(ids.device))
-    try:
-        caption, cap_list = og.build_caption(cats)
-        tok = Tok()
-        ids = tok.encode(caption)
-        spans = og.phrase_spans(ids, [tok.encode(c, add_special_tokens=False) for c in cap_list])
-        mean = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1)
-        std = torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1)
-        x = ((inputs[0]["image"].float() - mean) / std)[[2, 1, 0]]
-        with torch.no_grad():
-            o = hf(pixel_values=x[None], input_ids=torch.tensor(ids)[None], return_dict=True)
-    finally:
-        mgd.generate_masks_with_special_tokens_and_transfer_map = orig
+    caption, cap_list = og.build_caption(cats)
+    tok = Tok()
+    ids = tok.encode(caption)
+    spans = og.phrase_spans(ids, [tok.encode(c, add_special_tokens=False) for c in cap_list])
+    mean = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1)
+    std = torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1)
+    x = ((inputs[0]["image"].float() - mean) / std)[[2, 1, 0]]
+    with upstream_position_ids(), torch.no_grad():
+        o = hf(pixel_values=x[None], input_ids=torch.tensor(ids)[None], return_dict=True)
     lg = torch.full((o.logits.shape[1], 256), float("-inf"))
     lg[:, :len(ids)] = o.logits[0][:, :len(ids)]
     bx, sc, cl = og.gdino_postprocess(lg, o.pred_boxes[0], spans, cap_list, [[c] for c in cats], x.shape[1:])
@@ -379,3 +355,60 @@ def test_roiheads3dgdino_end_to_end_vs_hf_and_oracle(device):
     assert_close(got.pred_center_cam, ref["pred_center_cam"], 1e-3, "centre")
     assert_close(got.pred_dimensions, ref["pred_dimensions"], 1e-3, "dimensions")
     assert_close(got.pred_pose, ref["pred_pose"], 1e-3, "pose")
+
+
+def test_headline_config_on_coco_example_vs_hf_and_oracle(device):
+    """BASELINE configs[0]/[1] at their own size on a real demo input (reference datasets/coco_examples/000000101762.jpg,
+    480x640 -> ResizeShortestEdge(532, 896) -> 532x709, categories from its labels.json; copied as data under tests/golden/):
+    DINOv2 ViT-L/14 on the 896 canvas (T = 4097) + SFP + ROIHeads3DGDINO with the full-size native GroundingDINO (Swin-B,
+    BERT-base, 900 queries) + cube head, against [HF GroundingDINO fp32 on the CPU -> oracle glue -> oracle ViT-L / SFP / cube
+    head / decode / postprocess] on the same pixels, caption and random-init weights. Detections are paired by their 2D boxes
+    (near-tied proposals may be ordered differently by the two routes); every pair must agree in class id and within 1e-3."""
+    import os
+    import numpy as np
+    from common import GOLDEN, build_cfg, oracle_params
+    from oracle import gdino_glue as og
+    from oracle.pipeline import inference
+    from parity import parity_ok, parity_report
+    from ovmono3d_amd.data import ResizeShortestEdge, read_image
+    from ovmono3d_amd.gdino.detector import HashTokenizer, NativeGroundingDino
+    from ovmono3d_amd.modeling import build_model
+    from ovmono3d_amd.util.synth_gdino import synth_gdino_model
+    from ovmono3d_amd.util.synth_weights import synth_state_dict
+    torch.set_num_threads(16)
+    cats = ["bicycle", "cat"]                                                    # labels.json entry of this image
+    im = read_image(os.path.join(GOLDEN, "coco_000000101762.jpg"), "BGR")       # demo.py:52
+    h, w = im.shape[:2]
+    assert (h, w) == (480, 640)
+    net = ResizeShortestEdge(532, 896)(im)
+    assert net.shape[:2] == (532, 709)                                           # SURVEY.md Appendix B row 1
+    f = 4.0 * h / 2                                                              # demo.py:63-76
+    image = torch.as_tensor(np.ascontiguousarray(net.transpose(2, 0, 1)))
+    inp = {"image": image, "height": h, "width": w, "K": [[f, 0.0, w / 2], [0.0, f, h / 2], [0.0, 0.0, 1.0]]}
+    cfg = build_cfg("vitl14", 896, "f16x3", max_batch=1, max_rois=1000, roi_heads="ROIHeads3DGDINO")
+    model = build_model(cfg, device=device)
+    sd = synth_state_dict("vitl14", seed=0)
+    model.load_state_dict(sd)
+    hf, gd_sd = synth_gdino_model(0)
+    _patch_hf_to_upstream(hf)
+    tok = HashTokenizer()
+    model.roi_heads.detector = NativeGroundingDino(device, gd_sd, tok, cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD)
+    got = model([dict(inp, image=image.to(device), category_list=cats)])[0]["instances"]
+
+    caption, cap_list = og.build_caption(cats)
+    ids = tok.encode(caption)
+    spans = og.phrase_spans(ids, [tok.encode(c, add_special_tokens=False) for c in cap_list])
+    mean = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1)
+    std = torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1)
+    x = ((image.float() - mean) / std)[[2, 1, 0]]
+    with upstream_position_ids(), torch.no_grad():
+        o = hf(pixel_values=x[None], input_ids=torch.tensor(ids)[None], return_dict=True)
+    lg = torch.full((o.logits.shape[1], 256), float("-inf"))
+    lg[:, :len(ids)] = o.logits[0][:, :len(ids)]
+    bx, sc, cl = og.gdino_postprocess(lg, o.pred_boxes[0], spans, cap_list, [[c] for c in cats], x.shape[1:])
+    with torch.no_grad():
+        ref = inference(sd, [inp], oracle_params(cfg), given_boxes=[dict(pred_boxes=bx, pred_classes=cl, scores=sc)])[0]
+    rep = parity_report(got, ref)
+    print("headline-size parity on the COCO example:", rep)
+    assert rep["n_det_oracle"] >= 20
+    assert parity_ok(rep, 1e-3), rep

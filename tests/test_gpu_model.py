@@ -130,3 +130,55 @@ def test_rpn_boxhead_path_tiny_vit(device):
     assert len(out[0]["instances"]) > 0
     _compare(out, ref)
     assert out[0]["instances"].has("pred_bbox3D")
+
+
+def test_oracle2d_vitl_canvas896_headline_size(device):
+    """The bench's ViT configuration at its own size: ViT-L/14 (24 layers, D = 1024), SQUARE_PAD 896 (T = 4097), one 532x532
+    image, 32 given boxes, against the CPU oracle (rcnn3d.py:79-117). Measures the f16x3 error
+    growth over 24 layers on the kernels themselves instead of arguing it from an emulation."""
+    from oracle.pipeline import inference
+    cfg = build_cfg("vitl14", 896, "f16x3", max_batch=1, max_rois=64)
+    model, sd = _build(cfg, seed=0)
+    inputs = synth_inputs(1, hw=((532, 532),), orig_scale=512.0 / 532.0, n_boxes=32, seed=11)
+    out = model(inputs)
+    torch.set_num_threads(16)
+    ref, aux = inference(sd, inputs, oracle_params(cfg), return_aux=True)
+    model.backbone.export_features = True
+    feats = model.backbone(model.preprocess_image(inputs))
+    for k in ("p2", "p3", "p4"):
+        e = assert_close(feats[k], aux["features"][k], 1e-3, k)
+        print(f"ViT-L/896 {k}: scale-relative error {e:.2e}")
+    _compare(out, ref)
+
+
+def test_config5_geometry_vitl_width_canvas1036_batch2(device):
+    """BASELINE config 5 geometry: 1024x1024 inputs need SQUARE_PAD 1036 -> 74x74 patches,
+    T = 5477 (= 21 x 256 + 101 queries: a partial last attention block), p2/p3/p4 = 148/74/37 (odd p4), batch 2, ViT-L width at
+    depth 2, two image shapes, against the CPU oracle."""
+    from oracle.pipeline import inference
+    cfg = build_cfg("vitl14_d2", 1036, "f16x3", max_batch=2, max_rois=64)
+    model, sd = _build(cfg, seed=4)
+    inputs = synth_inputs(2, hw=((1024, 1024), (768, 1024)), orig_scale=1.0, n_boxes=24, seed=12)
+    out = model(inputs)
+    torch.set_num_threads(16)
+    ref, aux = inference(sd, inputs, oracle_params(cfg), return_aux=True)
+    model.backbone.export_features = True
+    feats = model.backbone(model.preprocess_image(inputs))
+    assert tuple(feats["p4"].shape[-2:]) == (37, 37) and tuple(feats["p2"].shape[-2:]) == (148, 148)
+    for k in ("p2", "p3", "p4"):
+        assert_close(feats[k], aux["features"][k], 2e-4, k)
+    _compare(out, ref)
+
+
+def test_inference_on_dataset_empty_image_between_nonempty(device):
+    """An image without detections between two with detections, through the per-rank loop (reference
+    omni3d_evaluation.py:626-734): the records of all three concatenate on the model's device and keep dataset order."""
+    from ovmono3d_amd.evaluation import inference_on_dataset
+    cfg = build_cfg("vittest14", 224, "f16x3", max_batch=1)
+    model, sd = _build(cfg)
+    inputs = synth_inputs(3, n_boxes=4, seed=8)
+    inputs[1]["oracle2D"] = {"gt_bbox2D": torch.zeros(0, 4), "gt_classes": torch.zeros(0, dtype=torch.int64)}
+    res = inference_on_dataset(model, [[d] for d in inputs])
+    assert [len(r["instances"]) for r in res] == [4, 0, 4] and [r["image_id"] for r in res] == [0, 1, 2]
+    solo = model([inputs[2]])[0]["instances"]
+    assert abs(res[2]["instances"][0]["score"] - float(solo.scores[0])) < 1e-7

@@ -123,7 +123,7 @@ def _attn_ref(qkv, B, T, heads):
 @pytest.mark.parametrize("precision", [1, 3])
 @pytest.mark.parametrize("waves", [4, 8])
 def test_attention(device, B, T, heads, precision, waves):
-    """waves = 8: the 256-query workgroup variant the engine uses in co-run mode (one workgroup per CU)."""
+    """waves = 8: the 256-query workgroup variant the engine uses by default; waves = 4: the co-run variant (one workgroup per CU)."""
     g = torch.Generator().manual_seed(T)
     qkv = (torch.randn(B * T, 3 * heads * 64, generator=g) * 1.5).to(device)
     out = torch.empty(B * T, heads * 64, device=device)

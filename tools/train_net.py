@@ -6,7 +6,8 @@ dataset (the reference's ``eval_helper.save_predictions``, tools/train_net.py:10
 
 Launch: ``python tools/train_net.py --eval-only --config-file configs/OVMono3D_dinov2_SFP.yaml --num-gpus N
 MODEL.WEIGHTS <ckpt> OUTPUT_DIR <dir>`` (N > 1 re-launches itself under torch.distributed.run, one rank
-per GPU over RCCL). Training (``do_train``) and the AP evaluators are out of scope.
+per GPU over RCCL). Rank 0 then runs the Omni3D AP evaluator (``evaluation/omni3d_eval.py``: AP2D / AP3D with true 3D IoU,
+written to ``omni_ap.json``). Training (``do_train``) is out of scope.
 
 Deviations from the fork, both restoring upstream intent: oracle-2D boxes are
 forwarded to the model when TEST.ORACLE2D is set and the oracle file exists, and TEST.CAT_MODE selects the mode.
@@ -33,6 +34,20 @@ from ovmono3d_amd.modeling import build_model  # noqa: E402
 logger = logging.getLogger("cubercnn")
 
 
+def oracle2d_file(cfg, mode, name, datasets_root):
+    """cfg.DATASETS.ORACLE2D_FILES[EVAL_MODE][mode][dataset] (reference config.py:42-76, consumed at
+    cubercnn/data/build.py:45-54): the configured path as given, else its base name under --datasets-root."""
+    files = cfg.DATASETS.ORACLE2D_FILES.get(cfg.DATASETS.ORACLE2D_FILES.EVAL_MODE, None)
+    split = files.get(mode, None) if files is not None and hasattr(files, "get") else None
+    path = split.get(name, None) if split is not None and hasattr(split, "get") else None
+    if not path:
+        return None
+    for cand in (path, os.path.join(datasets_root, os.path.basename(path))):
+        if os.path.exists(cand):
+            return cand
+    return None
+
+
 def do_test(cfg, model, mode="base", datasets_root="datasets/Omni3D", image_root="datasets", depth_dir=None):
     if mode == "novel":
         names = cfg.DATASETS.TEST_NOVEL
@@ -44,10 +59,12 @@ def do_test(cfg, model, mode="base", datasets_root="datasets/Omni3D", image_root
     for name in names:
         dicts = load_omni3d_json(os.path.join(datasets_root, name + ".json"), image_root)
         if cfg.TEST.ORACLE2D:
-            files = cfg.DATASETS.ORACLE2D_FILES.get(cfg.DATASETS.ORACLE2D_FILES.EVAL_MODE, {})
-            path = (files.get(mode, {}) or {}).get(name) if hasattr(files, "get") else None
-            if path and os.path.exists(path):
+            path = oracle2d_file(cfg, mode, name, datasets_root)
+            if path:
                 merge_oracle2d_to_detection_dicts(dicts, path)
+            else:
+                logger.warning("%s: TEST.ORACLE2D is set but no oracle-2D file was found (DATASETS.ORACLE2D_FILES.%s.%s); "
+                               "running the RPN + box-head path", name, cfg.DATASETS.ORACLE2D_FILES.EVAL_MODE, mode)
         loader = build_detection_test_loader(cfg, dicts, DatasetMapper3D(cfg, False, depth_dir), get_rank(), get_world_size())
         results = inference_on_dataset(model, loader, Omni3DEvaluator(name, out_dir))
         if get_rank() == 0:
@@ -79,6 +96,10 @@ def main(args):
     if not args.eval_only:
         raise SystemExit("only --eval-only is supported by the native inference path (training is out of scope)")
     model = build_model(cfg, device=torch.device("cuda", local_rank))
+    if world > 1:
+        # the record gather goes through libovm3d's own RCCL communicator (ovm_gather_records), as for a non-Python host
+        from ovmono3d_amd.evaluation.distributed import NativeComm, set_native_comm
+        set_native_comm(NativeComm.from_torch_distributed(torch.device("cuda", local_rank)))
     DetectionCheckpointer(model, save_dir=cfg.OUTPUT_DIR).resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume)
     if cfg.TEST.CAT_MODE == "all":
         do_test(cfg, model, "novel", args.datasets_root, args.image_root, args.depth_dir)
