@@ -204,8 +204,48 @@ int ovm_gdino_postprocess(const float* pred_logits, int32_t nq, int32_t ld, cons
                           int32_t n_phrases, int32_t img_h, int32_t img_w, float box_threshold, float nms_threshold,
                           float* out_boxes, float* out_scores, int32_t* out_classes, int32_t* n_out, ovm_stream_t stream);
 
+/* --- GroundingDINO network of ROIHeads3DGDINO as ONE call (ovm_gdino_forward). Replaces
+ * `load_model("./configs/GroundingDINO_SwinB_cfg.py", "./checkpoints/groundingdino_swinb_cogcoor.pth")` and
+ * `model(image[None], captions=[caption])` of reference cubercnn/modeling/roi_heads/roi_heads_gdino.py:16-23,186 (network:
+ * IDEA-Research/GroundingDINO @856dde2, configs/GroundingDINO_SwinB_cfg.py:1-43). The handle owns the packed weights; per
+ * (image size, caption) it builds a plan (index maps, masks, position tables, activation arena) once and replays the forward
+ * as a single HIP graph afterwards. Weights are named as in the Hugging Face port (upstream checkpoints are renamed by the host,
+ * ovmono3d_amd/gdino/detector.py:convert_upstream_state_dict). */
+typedef struct OvmGdino OvmGdino;
+typedef struct OvmGdinoConfig {
+  int32_t d_model, enc_layers, dec_layers, heads, ffn_dim;        /* cfg:9-15: 256, 6, 6, 8, 2048 */
+  int32_t n_levels, n_points, num_queries, max_text_len;          /* cfg:19-21,16,33: 4, 4, 900, 256 */
+  float pe_temperature, eps;                                      /* cfg:4-6: 20; LayerNorm eps 1e-5 */
+  int32_t bert_heads;                                             /* bert-base-uncased: 12 */
+  int32_t swin_embed, swin_depths[4], swin_heads[4], swin_window; /* swin_B_384_22k (cfg:3): 128, 2/2/18/2, 4/8/16/32, 12 */
+  float pixel_mean[3], pixel_std[3];                              /* MODEL.PIXEL_MEAN / STD in tensor channel order */
+  int32_t flip_channels;                                          /* 1: the reference's images[0][[2,1,0]] (roi_heads_gdino.py:146) */
+  int32_t precision;                                              /* 1 = fp16 operands, 3 = split fp16 (default) */
+  int32_t use_graphs;                                             /* capture each plan's forward into a HIP graph */
+  int32_t max_plans;                                              /* plans kept (LRU); 0 = 16 */
+} OvmGdinoConfig;
+int ovm_gdino_create(const OvmGdinoConfig* cfg, const OvmTensor* weights, int32_t n_weights, int32_t device, OvmGdino** out);
+int ovm_gdino_destroy(OvmGdino* g);
+const char* ovm_gdino_last_error(const OvmGdino* g);
+/* image: uint8 at network resolution (device). token_ids: host int32 [ntok] = tokenizer(caption) incl. [CLS] / [SEP];
+ * position_ids: host int32 [ntok] or NULL (upstream numbering: restart per phrase, delimiter included).
+ * pred_logits: device fp32 [num_queries][max_text_len], pre-sigmoid, -inf beyond the caption; pred_boxes: device fp32
+ * [num_queries][4] (cx, cy, w, h in [0, 1]). Either output may be NULL (results stay in the handle for ovm_gdino_detect). */
+int ovm_gdino_forward(OvmGdino* g, const OvmImage* image, const int32_t* token_ids, int32_t ntok, const int32_t* position_ids,
+                      float* pred_logits, float* pred_boxes, ovm_stream_t stream);
+/* forward + the reference-owned output glue (ovm_gdino_postprocess below; roi_heads_gdino.py:186-202,236-263): outputs as there. */
+int ovm_gdino_detect(OvmGdino* g, const OvmImage* image, const int32_t* token_ids, int32_t ntok, const int32_t* spans, int32_t n_phrases,
+                     float box_threshold, float nms_threshold, float* out_boxes, float* out_scores, int32_t* out_classes, int32_t* n_out,
+                     ovm_stream_t stream);
+/* tests: pin the two-stage top-k selection to the given device int32 [num_queries] (NULL: the network's own) */
+int ovm_gdino_set_force_topk(OvmGdino* g, const int32_t* idx_device);
+/* tests: copy an intermediate of the last forward ("bert_out", "text_features", "swin_stage1..3", "enc_vision", "enc_text",
+ * "topk" (int32), "init_ref") into dst; returns the element count. name "launches": returns the kernel launches per forward. */
+int64_t ovm_gdino_debug_copy(OvmGdino* g, const char* name, void* dst, int64_t capacity_elems, ovm_stream_t stream);
+
 /* --- generic device ops the GroundingDINO branch (ROIHeads3DGDINO's network, reference roi_heads_gdino.py:186) is
- * sequenced from: fp32 row-major tensors in HBM, one call per op, all arithmetic on the device. */
+ * was sequenced from in round 1 (still exported: unit tests and the Python-sequenced cross-check path use them): fp32
+ * row-major tensors in HBM, one call per op, all arithmetic on the device. */
 int ovm_g_pack_weight(const float* w, int32_t N, int32_t K, int32_t Kpad, uint16_t* hi, uint16_t* lo, ovm_stream_t stream);
 int ovm_g_linear(const float* x, int32_t ldx, int32_t M, int32_t K, const uint16_t* w_hi, const uint16_t* w_lo, int32_t N, int32_t Kpad,
                  const float* bias, int32_t act /* 0 none, 1 relu, 2 gelu */, const float* residual, int32_t ldr, float* y, int32_t ldy,

@@ -5,6 +5,7 @@
 // (roi_heads.py:252-296) and fast_rcnn_inference_single_image (fast_rcnn.py:57-116); SURVEY.md Appendix
 // A4, A6, A10 for the third-party semantics (top-k per level, Box2BoxTransform, clip, batched NMS).
 #include "det2d.hpp"
+#include "gdino.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -651,6 +652,16 @@ __global__ void topk_emit_kernel(const unsigned long long* __restrict__ keys, in
   if (i < k) out[i] = (int)(keys[i] & kIdMask);
 }
 }  // namespace
+int launch_topk_keys(const float* scores, int n, int k, int* out_idx, unsigned long long* keys, int N, hipStream_t s) {
+  if (k > n || n <= 0 || N < pow2_at_least(n)) return OVM_ERR_INVALID;
+  N = pow2_at_least(n);
+  hipLaunchKernelGGL(single_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, s, scores, (const int*)nullptr, n, N, keys);
+  int r = sort_keys(keys, N, 1, s);
+  if (r) return r;
+  hipLaunchKernelGGL(topk_emit_kernel, dim3((k + 255) / 256), dim3(256), 0, s, keys, k, out_idx);
+  return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
+
 int launch_topk(const float* scores, int n, int k, int* out_idx, hipStream_t s) {
   if (k > n || n <= 0) return OVM_ERR_INVALID;
   const int N = pow2_at_least(n);

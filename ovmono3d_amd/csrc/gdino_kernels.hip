@@ -1,0 +1,565 @@
+// Fused device kernels of the native GroundingDINO engine (see gdino.hpp). gfx950, wave = 64.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include "gdino.hpp"
+
+namespace ovm {
+
+namespace {
+
+inline dim3 g1(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Row operator. One wave per output row; the row (after gather and residual) is held in registers when a LayerNorm needs two
+// passes over it, streamed otherwise.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int VEC> struct VecT;
+template <> struct VecT<4> { typedef f32x4 T; };
+template <> struct VecT<1> { typedef float T; };
+
+template <int VEC>
+__device__ __forceinline__ void rowop_load(const RowOpParams& p, int row, int e, float* v) {
+  // elements e .. e+VEC-1 of the gathered (+ residual) row; e % VEC == 0 and a VEC group never straddles a segment
+  int src = row, c = e;
+  if (p.idx) { const int j = e / p.seg; c = e - j * p.seg; src = p.idx[(size_t)row * p.nidx + j]; }
+  if (src < 0) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = 0.f;
+  } else if (VEC == 4) {
+    const f32x4 t = *(const f32x4*)(p.x + (size_t)src * p.ldx + c);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  } else {
+    v[0] = p.x[(size_t)src * p.ldx + c];
+  }
+  if (p.res) {
+    if (VEC == 4) { const f32x4 t = *(const f32x4*)(p.res + (size_t)row * p.ldr + e); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+    else v[0] += p.res[(size_t)row * p.ldr + e];
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void rowop_store(const RowOpParams& p, int row, int e, const float* y) {
+  if (p.y) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) p.y[(size_t)row * p.ldy + e + i] = y[i];
+  }
+  if (p.hi) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      half_t h, l; split_f16_nt(y[i], h, l);
+      p.hi[(size_t)row * p.ldh + e + i] = h;
+      if (p.lo) p.lo[(size_t)row * p.ldh + e + i] = l;
+    }
+  }
+  if (p.add) {
+    float y2[VEC];
+    const float* ar = p.add + (size_t)(row % p.add_rows) * p.ld_add + e;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) y2[i] = y[i] + ar[i];
+    if (p.y2) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) p.y2[(size_t)row * p.ldy2 + e + i] = y2[i];
+    }
+    if (p.hi2) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        half_t h, l; split_f16_nt(y2[i], h, l);
+        p.hi2[(size_t)row * p.ldh2 + e + i] = h;
+        if (p.lo2) p.lo2[(size_t)row * p.ldh2 + e + i] = l;
+      }
+    }
+  }
+}
+
+template <int VEC, int MAXV>
+__global__ __launch_bounds__(256) void rowop_kernel(const RowOpParams p) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= p.M) return;
+  const int D = p.D;
+  if (p.gamma) {
+    float v[MAXV][VEC];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int e = (lane + 64 * i) * VEC;
+      if (e < D) {
+        rowop_load<VEC>(p, row, e, v[i]);
+#pragma unroll
+        for (int r = 0; r < VEC; ++r) sum += v[i][r];
+      }
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int e = (lane + 64 * i) * VEC;
+      if (e < D) {
+#pragma unroll
+        for (int r = 0; r < VEC; ++r) { const float d = v[i][r] - mean; sq += d * d; }
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + p.eps);
+    const bool masked = p.zero_masked && p.idx && p.idx[(size_t)row * p.nidx] < 0;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int e = (lane + 64 * i) * VEC;
+      if (e < D) {
+        float y[VEC];
+#pragma unroll
+        for (int r = 0; r < VEC; ++r) y[r] = masked ? 0.f : (v[i][r] - mean) * rstd * p.gamma[e + r] + p.beta[e + r];
+        rowop_store<VEC>(p, row, e, y);
+      }
+    }
+  } else {
+    for (int e = lane * VEC; e < D; e += 64 * VEC) {
+      float v[VEC];
+      rowop_load<VEC>(p, row, e, v);
+      rowop_store<VEC>(p, row, e, v);
+    }
+  }
+  // zero fill of the K padding of the split images
+  if (p.hi && p.ldh > D)
+    for (int e = D + lane; e < p.ldh; e += 64) { p.hi[(size_t)row * p.ldh + e] = (half_t)0.f; if (p.lo) p.lo[(size_t)row * p.ldh + e] = (half_t)0.f; }
+  if (p.hi2 && p.ldh2 > D)
+    for (int e = D + lane; e < p.ldh2; e += 64) { p.hi2[(size_t)row * p.ldh2 + e] = (half_t)0.f; if (p.lo2) p.lo2[(size_t)row * p.ldh2 + e] = (half_t)0.f; }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// fp32 attention on the matrix cores. S^T = K Q^T per 16-key tile (A = K rows from LDS, B = the wave's 16 queries in
+// registers), so a lane's accumulator registers are 4 keys of ONE query (column = lane & 15): the softmax reduces over
+// registers and the 4 lane groups only, and the probabilities are directly the B operand of O^T = V^T P^T - no data movement
+// between the two products. v_mfma_f32_16x16x4_f32 is an exact fp32 FMA chain (MI355X_MICROARCH.md, Matrix cores).
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr int kKC = 144;                       // keys per LDS chunk (= one Swin window)
+
+template <int DH>
+__global__ __launch_bounds__(576) void attn_f32_kernel(const AttnF32Params p) {
+  constexpr int LDK = DH + 2, LDV = DH + 4, NS = DH / 4, ND = DH / 16, NKT = kKC / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* Ks = (float*)smem_raw;                // [kKC][LDK]
+  float* Vs = Ks + kKC * LDK;                  // [kKC][LDV]   (kKC * LDK * 4 is a multiple of 16)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
+  const int li = lane & 15, g = lane >> 4;
+  const int z = blockIdx.y, b1 = z / p.nb2, b2 = z - b1 * p.nb2;
+  const float* qb = p.q + (size_t)b1 * p.sq1 + (size_t)b2 * p.sq2;
+  const float* kb = p.k + (size_t)b1 * p.sk1 + (size_t)b2 * p.sk2;
+  const float* vb = p.v + (size_t)b1 * p.sv1 + (size_t)b2 * p.sv2;
+  const int q0 = (blockIdx.x * (nthr >> 6) + wave) * 16;
+  const bool wave_active = q0 < p.Tq;          // idle waves still help staging and must reach the barriers
+  const int qi = (q0 + li < p.Tq) ? q0 + li : p.Tq - 1;
+  const float kLog2e = 1.44269504088896340736f;
+  float qf[NS];
+  {
+    const float sc = p.scale * kLog2e;
+    const float* qr = qb + (size_t)qi * p.ldq;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qf[s] = qr[4 * s + g] * sc;
+  }
+  const float* bh = p.bias_h ? p.bias_h + (size_t)b2 * p.sbh + (size_t)qi * p.ldbh : nullptr;
+  const float* bb = p.bias_b ? p.bias_b + (size_t)b1 * p.sbb + (size_t)qi * p.ldbb : nullptr;
+  f32x4 o[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+
+  for (int kc = 0; kc < p.Tk; kc += kKC) {
+    __syncthreads();
+    // stage K / V rows kc .. kc+kKC (zero beyond Tk): DH/4 float4 pieces per row
+    for (int t = tid; t < kKC * (DH / 4); t += nthr) {
+      const int r = t / (DH / 4), c = (t - r * (DH / 4)) * 4;
+      f32x4 kv = (f32x4){0.f, 0.f, 0.f, 0.f}, vv = kv;
+      if (kc + r < p.Tk) {
+        kv = *(const f32x4*)(kb + (size_t)(kc + r) * p.ldk + c);
+        vv = *(const f32x4*)(vb + (size_t)(kc + r) * p.ldv + c);
+      }
+      float* kd = Ks + r * LDK + c;
+      kd[0] = kv[0]; kd[1] = kv[1]; kd[2] = kv[2]; kd[3] = kv[3];
+      *(f32x4*)(Vs + r * LDV + c) = vv;
+    }
+    __syncthreads();
+    if (!wave_active) continue;
+    const int nk = (p.Tk - kc < kKC) ? p.Tk - kc : kKC;
+    const int nkt = (nk + 15) >> 4;
+    f32x4 st[NKT];
+    float cmax = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt < nkt) {                          // wave-uniform
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* kr = Ks + (kt * 16 + li) * LDK + g;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[4 * s], qf[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kc + kt * 16 + g * 4 + r;
+          float x = acc[r];
+          if (key < p.Tk) {
+            if (bh) x += bh[key] * kLog2e;
+            if (bb) x += bb[key] * kLog2e;
+          } else {
+            x = -INFINITY;
+          }
+          acc[r] = x;
+          cmax = fmaxf(cmax, x);
+        }
+        st[kt] = acc;
+      } else {
+        st[kt] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      }
+    }
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+    const float mnew = fmaxf(m, cmax);
+    const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+    const float alpha = exp2f(m - msafe);      // m = -inf -> 0
+    l *= alpha;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) { o[d][0] *= alpha; o[d][1] *= alpha; o[d][2] *= alpha; o[d][3] *= alpha; }
+    m = mnew;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt < nkt) {
+        f32x4 pr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pr[r] = exp2f(st[kt][r] - msafe); l += pr[r]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* vr = Vs + (kt * 16 + g * 4 + r) * LDV + li;
+#pragma unroll
+          for (int d = 0; d < ND; ++d) o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[d * 16], pr[r], o[d], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (!wave_active) return;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+  if (q0 + li < p.Tq) {
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+      const f32x4 y = (f32x4){o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv};
+      const int col = d * 16 + g * 4;
+      if (p.o) *(f32x4*)(p.o + (size_t)b1 * p.so1 + (size_t)b2 * p.so2 + (size_t)(q0 + li) * p.ldo + col) = y;
+      if (p.ohi) {
+        half4 h, lo4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { half_t hh, ll; split_f16_nt(y[r], hh, ll); h[r] = hh; lo4[r] = ll; }
+        const size_t oo = (size_t)b1 * p.soh1 + (size_t)b2 * p.soh2 + (size_t)(q0 + li) * p.ldoh + col;
+        *(half4*)(p.ohi + oo) = h;
+        if (p.olo) *(half4*)(p.olo + oo) = lo4;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Fusion-layer bi-attention.
+// ------------------------------------------------------------------------------------------------------------------------------
+// image side: one wave per (image token, head); online softmax over the text tokens; also leaves the raw scores for the text side
+__global__ __launch_bounds__(256) void biattn_img_kernel(const BiAttnParams p) {
+  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (wid >= (long)p.S * p.H) return;
+  const int s = (int)(wid / p.H), h = (int)(wid - (long)s * p.H);
+  const int dh = p.dh;
+  constexpr int MAXE = 2;                       // dh <= 512
+  f32x4 qv[MAXE], acc[MAXE];
+#pragma unroll
+  for (int i = 0; i < MAXE; ++i) {
+    const int e = (lane + 64 * i) * 4;
+    qv[i] = (e < dh) ? *(const f32x4*)(p.qv + (size_t)s * p.ldq + h * dh + e) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  float m = -INFINITY, l = 0.f;
+  for (int t = 0; t < p.T; ++t) {
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+      const int e = (lane + 64 * i) * 4;
+      if (e < dh) {
+        const f32x4 kv = *(const f32x4*)(p.kt + (size_t)t * p.ldk + h * dh + e);
+        d += qv[i][0] * kv[0] + qv[i][1] * kv[1] + qv[i][2] * kv[2] + qv[i][3] * kv[3];
+      }
+    }
+    d = wave_sum(d) * p.scale;
+    if (lane == 0) p.sc[((size_t)h * p.T + t) * p.S + s] = d;
+    const float mn = fmaxf(m, d);
+    const float alpha = expf(m - mn), pr = expf(d - mn);
+    l = l * alpha + pr;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+      const int e = (lane + 64 * i) * 4;
+      if (e < dh) {
+        const f32x4 tv = *(const f32x4*)(p.vt + (size_t)t * p.ldvt + h * dh + e);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = acc[i][r] * alpha + pr * tv[r];
+      }
+    }
+    m = mn;
+  }
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int i = 0; i < MAXE; ++i) {
+    const int e = (lane + 64 * i) * 4;
+    if (e < dh) {
+      const f32x4 y = (f32x4){acc[i][0] * inv, acc[i][1] * inv, acc[i][2] * inv, acc[i][3] * inv};
+      if (p.cv) *(f32x4*)(p.cv + (size_t)s * p.ldcv + h * dh + e) = y;
+      if (p.cv_hi) {
+        half4 hh, ll;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { half_t a, b; split_f16_nt(y[r], a, b); hh[r] = a; ll[r] = b; }
+        *(half4*)(p.cv_hi + (size_t)s * p.ldcv + h * dh + e) = hh;
+        if (p.cv_lo) *(half4*)(p.cv_lo + (size_t)s * p.ldcv + h * dh + e) = ll;
+      }
+    }
+  }
+}
+
+// text side, softmax statistics over the image tokens: one workgroup per (head, text token)
+__global__ __launch_bounds__(256) void biattn_stats_kernel(const BiAttnParams p) {
+  __shared__ float red[8];
+  const int ht = blockIdx.x;
+  const float* row = p.sc + (size_t)ht * p.S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float m = -INFINITY;
+  for (int i = tid; i < p.S; i += 256) m = fmaxf(m, row[i]);
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.f;
+  for (int i = tid; i < p.S; i += 256) s += expf(row[i] - m);
+  s = wave_sum(s);
+  if (lane == 0) red[4 + wave] = s;
+  __syncthreads();
+  if (tid == 0) { p.stat[2 * ht] = m; p.stat[2 * ht + 1] = (red[4] + red[5]) + (red[6] + red[7]); }
+}
+
+// text side, partial context of one chunk of image tokens: part[c][t][h*dh + d] = sum_{s in chunk} exp(sc - max) vv[s][h*dh + d]
+__global__ __launch_bounds__(256) void biattn_txt_partial_kernel(const BiAttnParams p) {
+  constexpr int TB = 16, CH = 128;
+  __shared__ float pr[TB][CH];
+  const int c = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+  const int s0 = c * p.chunk;
+  const int ns = (p.S - s0 < p.chunk) ? p.S - s0 : p.chunk;   // chunk <= CH
+  const int E = p.H * p.dh;
+  for (int t0 = 0; t0 < p.T; t0 += TB) {
+    const int nt = (p.T - t0 < TB) ? p.T - t0 : TB;
+    __syncthreads();
+    for (int i = tid; i < TB * CH; i += 256) {
+      const int t = i / CH, si = i - t * CH;
+      float v = 0.f;
+      if (t < nt && si < ns) v = expf(p.sc[((size_t)h * p.T + t0 + t) * p.S + s0 + si] - p.stat[2 * (h * p.T + t0 + t)]);
+      pr[t][si] = v;
+    }
+    __syncthreads();
+    for (int d = tid; d < p.dh; d += 256) {
+      float acc[TB];
+#pragma unroll
+      for (int t = 0; t < TB; ++t) acc[t] = 0.f;
+      const float* vcol = p.vv + (size_t)s0 * p.ldvv + h * p.dh + d;
+      for (int si = 0; si < ns; ++si) {
+        const float x = vcol[(size_t)si * p.ldvv];
+#pragma unroll
+        for (int t = 0; t < TB; ++t) acc[t] = fmaf(pr[t][si], x, acc[t]);
+      }
+      for (int t = 0; t < nt; ++t) p.part[((size_t)c * p.T + t0 + t) * E + h * p.dh + d] = acc[t];
+    }
+  }
+}
+
+__global__ void biattn_txt_combine_kernel(const BiAttnParams p) {
+  const int E = p.H * p.dh;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)p.T * E) return;
+  const int t = (int)(i / E), e = (int)(i - (long)t * E), h = e / p.dh;
+  float acc = 0.f;
+  for (int c = 0; c < p.nchunk; ++c) acc += p.part[((size_t)c * p.T + t) * E + e];
+  p.ct[(size_t)t * E + e] = acc / p.stat[2 * (h * p.T + t) + 1];
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Multi-scale deformable attention (Deformable-DETR sampling = F.grid_sample bilinear, zeros padding, align_corners=False), one
+// thread per (query, head, channel); the softmax over the L*P logits and the sampling locations are computed inline.
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void msdeform_fused_kernel(const MsDeformParams p) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)p.Q * p.H * p.dh;
+  if (t >= total) return;
+  const int d = (int)(t % p.dh); long r = t / p.dh;
+  const int hh = (int)(r % p.H); const int q = (int)(r / p.H);
+  const int LP = p.L * p.P;
+  const float* offp = p.ow + (size_t)q * p.ldow + (size_t)hh * LP * 2;
+  const float* lgp = p.ow + (size_t)q * p.ldow + (size_t)p.H * LP * 2 + (size_t)hh * LP;
+  float mx = -INFINITY;
+  for (int i = 0; i < LP; ++i) mx = fmaxf(mx, lgp[i]);
+  float den = 0.f;
+  for (int i = 0; i < LP; ++i) den += expf(lgp[i] - mx);
+  const float inv = 1.0f / den;
+  const float* rf = p.ref + (size_t)q * p.ldref;
+  const int HD = p.H * p.dh;
+  float acc = 0.f;
+  for (int l = 0; l < p.L; ++l) {
+    const int Hh = p.lh[l], Ww = p.lw[l];
+    const float* vb = p.value + (size_t)p.lstart[l] * p.ldv + (size_t)hh * p.dh + d;
+    float mulx, muly;
+    if (p.mode == 0) { mulx = 1.0f / (float)Ww; muly = 1.0f / (float)Hh; }
+    else { mulx = rf[2] * (0.5f / (float)p.P); muly = rf[3] * (0.5f / (float)p.P); }
+    for (int pt = 0; pt < p.P; ++pt) {
+      const float lx = __fadd_rn(__fmul_rn(offp[(l * p.P + pt) * 2], mulx), rf[0]);
+      const float ly = __fadd_rn(__fmul_rn(offp[(l * p.P + pt) * 2 + 1], muly), rf[1]);
+      const float gx = 2.f * lx - 1.f, gy = 2.f * ly - 1.f;
+      const float ix = ((gx + 1.f) * (float)Ww - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)Hh - 1.f) * 0.5f;
+      const float fx = floorf(ix), fy = floorf(iy);
+      const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+      const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+      float v = 0.f;
+      if (y0 >= 0 && y0 < Hh) {
+        if (x0 >= 0 && x0 < Ww) v += wy0 * wx0 * vb[(size_t)(y0 * Ww + x0) * p.ldv];
+        if (x1 >= 0 && x1 < Ww) v += wy0 * wx1 * vb[(size_t)(y0 * Ww + x1) * p.ldv];
+      }
+      if (y1 >= 0 && y1 < Hh) {
+        if (x0 >= 0 && x0 < Ww) v += wy1 * wx0 * vb[(size_t)(y1 * Ww + x0) * p.ldv];
+        if (x1 >= 0 && x1 < Ww) v += wy1 * wx1 * vb[(size_t)(y1 * Ww + x1) * p.ldv];
+      }
+      acc += v * (expf(lgp[l * p.P + pt] - mx) * inv);
+    }
+  }
+  (void)HD;
+  const int col = hh * p.dh + d;
+  if (p.out) p.out[(size_t)q * p.ldo + col] = acc;
+  if (p.ohi) {
+    half_t h, lo; split_f16(acc, h, lo);
+    p.ohi[(size_t)q * p.ldoh + col] = h;
+    if (p.olo) p.olo[(size_t)q * p.ldoh + col] = lo;
+  }
+}
+
+__global__ void box_refine_kernel(const float* __restrict__ delta, int ldd, const float* __restrict__ ref, float eps, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 4) return;
+  const int q = i >> 2, c = i & 3;
+  const float xc = fminf(fmaxf(ref[i], eps), 1.f - eps);
+  const float x = delta[(size_t)q * ldd + c] + logf(xc / (1.f - xc));          // torch.special.logit(x, eps)
+  out[i] = 1.0f / (1.0f + expf(-x));
+}
+
+__global__ void pad_logits_kernel(const float* __restrict__ x, int ldx, int Q, int T, float* __restrict__ out, int ld) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)Q * ld) return;
+  const int q = (int)(i / ld), c = (int)(i - (long)q * ld);
+  out[i] = (c < T) ? x[(size_t)q * ldx + c] : -INFINITY;
+}
+
+__global__ __launch_bounds__(256) void bert_embed_kernel(const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ typ,
+                                                         const int* __restrict__ ids, const int* __restrict__ pids, int T, int D,
+                                                         const float* __restrict__ g, const float* __restrict__ b, float eps, float* __restrict__ out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= T) return;
+  const float* w = word + (size_t)ids[row] * D; const float* pp = pos + (size_t)pids[row] * D;
+  // same association as the generic chain: (word + pos) + type
+  float s = 0.f;
+  for (int j = lane; j < D; j += 64) s += (w[j] + pp[j]) + typ[j];
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+  for (int j = lane; j < D; j += 64) { const float d = (w[j] + pp[j]) + typ[j] - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  for (int j = lane; j < D; j += 64) out[(size_t)row * D + j] = ((w[j] + pp[j]) + typ[j] - mean) * rstd * g[j] + b[j];
+}
+
+__global__ void select_ref_kernel(const float* __restrict__ coord, int ldc, const float* __restrict__ prop, const int* __restrict__ idx, int n,
+                                  float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 4) return;
+  const int q = i >> 2, c = i & 3;
+  const int s = idx[q];
+  const float x = coord[(size_t)s * ldc + c] + prop[(size_t)s * 4 + c];
+  out[i] = 1.0f / (1.0f + expf(-x));
+}
+
+}  // namespace
+
+int launch_rowop(const RowOpParams& p, hipStream_t s) {
+  if (p.M <= 0) return OVM_OK;
+  const int seg = p.idx ? p.seg : p.D;
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  const bool v4 = (p.D % 4 == 0) && (seg % 4 == 0) && (p.ldx % 4 == 0) && al16(p.x) && (!p.res || (p.ldr % 4 == 0 && al16(p.res)));
+  const dim3 grid((p.M + 3) / 4), block(256);
+  if (p.gamma) {
+    if (v4) {
+      if (p.D <= 1024) hipLaunchKernelGGL((rowop_kernel<4, 4>), grid, block, 0, s, p);
+      else if (p.D <= 4096) hipLaunchKernelGGL((rowop_kernel<4, 16>), grid, block, 0, s, p);
+      else return OVM_ERR_SHAPE;
+    } else {
+      if (p.D <= 1024) hipLaunchKernelGGL((rowop_kernel<1, 16>), grid, block, 0, s, p);
+      else return OVM_ERR_SHAPE;
+    }
+  } else {
+    if (v4) hipLaunchKernelGGL((rowop_kernel<4, 1>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((rowop_kernel<1, 1>), grid, block, 0, s, p);
+  }
+  return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
+
+int launch_attn_f32(const AttnF32Params& p, hipStream_t s) {
+  if (p.Tq <= 0 || p.Tk <= 0 || p.nb1 <= 0 || p.nb2 <= 0) return OVM_OK;
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  if (p.ldk % 4 || p.ldv % 4 || !al16(p.k) || !al16(p.v) || p.sk1 % 4 || p.sk2 % 4 || p.sv1 % 4 || p.sv2 % 4) return OVM_ERR_SHAPE;
+  if (p.o && (p.ldo % 4 || !al16(p.o) || p.so1 % 4 || p.so2 % 4)) return OVM_ERR_SHAPE;
+  if (p.ohi && (p.ldoh % 4 || p.soh1 % 4 || p.soh2 % 4)) return OVM_ERR_SHAPE;
+  // waves per workgroup: a whole Swin window (144 queries) in one workgroup, else 4 waves (64 queries)
+  int nw = (p.Tq + 15) / 16;
+  if (nw > 9) nw = 4;
+  const int qb = 16 * nw;
+  const dim3 grid((p.Tq + qb - 1) / qb, (unsigned)(p.nb1 * p.nb2)), block(64 * nw);
+  if ((long)p.nb1 * p.nb2 > 65535) return OVM_ERR_CAPACITY;
+#define OVM_ATTN_F32(DH_)                                                                              \
+  {                                                                                                    \
+    const int smem = kKC * ((DH_) + 2) * 4 + kKC * ((DH_) + 4) * 4;                                    \
+    static bool set = false;                                                                           \
+    if (!set && smem > 65536) { (void)hipFuncSetAttribute((const void*)attn_f32_kernel<DH_>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); set = true; } \
+    hipLaunchKernelGGL((attn_f32_kernel<DH_>), grid, block, smem, s, p);                               \
+  }
+  if (p.DH == 16) OVM_ATTN_F32(16)
+  else if (p.DH == 32) OVM_ATTN_F32(32)
+  else if (p.DH == 64) OVM_ATTN_F32(64)
+  else return OVM_ERR_SHAPE;
+#undef OVM_ATTN_F32
+  return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
+
+int launch_biattn(const BiAttnParams& p, hipStream_t s) {
+  if (p.dh % 4 || p.dh > 512 || p.chunk > 128 || p.chunk <= 0) return OVM_ERR_SHAPE;
+  hipLaunchKernelGGL(biattn_img_kernel, dim3((unsigned)(((long)p.S * p.H + 3) / 4)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(biattn_stats_kernel, dim3(p.H * p.T), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(biattn_txt_partial_kernel, dim3(p.nchunk, p.H), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(biattn_txt_combine_kernel, g1((long)p.T * p.H * p.dh), dim3(256), 0, s, p);
+  return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
+
+int launch_msdeform_fused(const MsDeformParams& p, hipStream_t s) {
+  if (p.L > 8 || p.Q <= 0) return p.Q <= 0 ? OVM_OK : OVM_ERR_CAPACITY;
+  hipLaunchKernelGGL(msdeform_fused_kernel, g1((long)p.Q * p.H * p.dh), dim3(256), 0, s, p);
+  return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
+
+int launch_box_refine(const float* delta, int ldd, const float* ref, float eps, float* out, int n, hipStream_t s) {
+  hipLaunchKernelGGL(box_refine_kernel, g1((long)n * 4), dim3(256), 0, s, delta, ldd, ref, eps, out, n);
+  return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
+int launch_pad_logits(const float* x, int ldx, int Q, int T, float* out, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(pad_logits_kernel, g1((long)Q * ld), dim3(256), 0, s, x, ldx, Q, T, out, ld);
+  return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
+int launch_bert_embed(const float* word, const float* pos, const float* typ, const int* ids, const int* pids, int T, int D, const float* g,
+                      const float* b, float eps, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(bert_embed_kernel, dim3((T + 3) / 4), dim3(256), 0, s, word, pos, typ, ids, pids, T, D, g, b, eps, out);
+  return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
+int launch_select_ref(const float* coord, int ldc, const float* prop_logit, const int* idx, int n, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(select_ref_kernel, g1((long)n * 4), dim3(256), 0, s, coord, ldc, prop_logit, idx, n, out);
+  return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
+
+}  // namespace ovm

@@ -63,13 +63,18 @@ static int launch_ws(const GemmParams& p, hipStream_t s) {
       const int chunk = (nk + ks - 1) / ks;
       ks = (nk + chunk - 1) / chunk;
       const size_t need = (size_t)ks * p.M * p.N * sizeof(float);
-      float*& g_splitk_ws = g_splitk_ws_[p.ws_slot & 1]; size_t& g_splitk_cap = g_splitk_cap_[p.ws_slot & 1];
-      if (g_splitk_cap < need) {
-        if (g_splitk_ws) { (void)hipDeviceSynchronize(); (void)hipFree(g_splitk_ws); }
-        g_splitk_cap = need + need / 2 + (1 << 20);
-        if (hipMalloc((void**)&g_splitk_ws, g_splitk_cap) != hipSuccess) { g_splitk_ws = nullptr; g_splitk_cap = 0; return OVM_ERR_HIP; }
+      if (p.part_ws) {                                         // caller-owned (graph-safe) workspace
+        if (p.part_cap < need) return OVM_ERR_CAPACITY;
+        q.ksplit = ks; q.kchunk = chunk; q.part = p.part_ws;
+      } else {
+        float*& g_splitk_ws = g_splitk_ws_[p.ws_slot & 1]; size_t& g_splitk_cap = g_splitk_cap_[p.ws_slot & 1];
+        if (g_splitk_cap < need) {
+          if (g_splitk_ws) { (void)hipDeviceSynchronize(); (void)hipFree(g_splitk_ws); }
+          g_splitk_cap = need + need / 2 + (1 << 20);
+          if (hipMalloc((void**)&g_splitk_ws, g_splitk_cap) != hipSuccess) { g_splitk_ws = nullptr; g_splitk_cap = 0; return OVM_ERR_HIP; }
+        }
+        q.ksplit = ks; q.kchunk = chunk; q.part = g_splitk_ws;
       }
-      q.ksplit = ks; q.kchunk = chunk; q.part = g_splitk_ws;
     }
   }
   int tail_blocks = 0;

@@ -32,6 +32,8 @@ struct GemmParams {
   // split-K (wave-specialised kernel, set by the launcher for thin grids with a long K): workgroup = (tile, k-slice); slices
   // write raw fp32 partial tiles to `part` [ksplit][M][N] and splitk_epilogue_kernel sums them and applies the epilogue
   int ksplit, kchunk; float* part;
+  float* part_ws; size_t part_cap;                // caller-owned split-K workspace (bytes); null: the launcher's process-global one
+                                                  // (which may be re-allocated - not usable under HIP-graph capture / replay)
   int ws_slot;                                    // which split-K workspace the launcher may use: callers that run concurrently on
                                                   // different streams (engine = 0, generic GroundingDINO ops = 1) must not share one
   int M, N, K;
@@ -40,7 +42,9 @@ struct GemmParams {
   // epilogue operands
   const float* bias;                              // [N] or null
   const float* gamma;                             // EPI_RESID: LayerScale [N]
-  float* X; int ldx;                              // EPI_RESID: fp32 residual stream, in place
+  float* X; int ldx;                              // EPI_RESID: fp32 residual stream, in place (gamma null: plain residual)
+  const int* row_map;                             // EPI_RESID: optional, row m updates X[row_map[m]] (negative: dropped) - the
+                                                  // reverse window partition / un-shift / crop of a Swin block
   float* C; int ldc;                              // EPI_STORE: fp32 out (or null)
   half_t* Ohi; half_t* Olo; int ldo;              // EPI_STORE / EPI_GELU / EPI_CONVT: fp16 split out (or null)
   int relu;                                       // EPI_STORE activation: 0 none, 1 ReLU, 2 GELU(erf)
@@ -126,15 +130,17 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32
   }
   const bool full = (n + 3 < p.N);
   if (EPI == EPI_RESID) {
-    float* x = p.X + (size_t)m * p.ldx + n;
+    int mr = m;
+    if (p.row_map) { mr = p.row_map[m]; if (mr < 0) return; }
+    float* x = p.X + (size_t)mr * p.ldx + n;
     if (full) {
       f32x4 xv = *(const f32x4*)x;
-      const f32x4 g = *(const f32x4*)(p.gamma + n);
+      const f32x4 g = p.gamma ? *(const f32x4*)(p.gamma + n) : (f32x4){1.f, 1.f, 1.f, 1.f};
 #pragma unroll
       for (int r = 0; r < 4; ++r) xv[r] += g[r] * (v[r] + b4[r]);
       *(f32x4*)x = xv;
     } else {
-      for (int r = 0; r < 4 && n + r < p.N; ++r) x[r] += p.gamma[n + r] * (v[r] + b4[r]);
+      for (int r = 0; r < 4 && n + r < p.N; ++r) x[r] += (p.gamma ? p.gamma[n + r] : 1.f) * (v[r] + b4[r]);
     }
   } else if (EPI == EPI_GELU) {
     half4 h, l;
@@ -677,6 +683,11 @@ void gemm_set_splitk(int v);
 bool gemm_small_supported(const float* A, int lda, int K);
 int launch_gemm_small(const float* A, int lda, int M, int K, const half_t* Whi, const half_t* Wlo, int N, int Kpad, const float* bias, int act,
                       const float* R, int ldr, float* C, int ldc, int npass, hipStream_t s);
+// same with an optional second A term (x = A + A2, same row stride; e.g. the position embedding added to attention queries / keys)
+// and a caller-owned split-K workspace (null: the process-global one, not usable under HIP-graph capture)
+int launch_gemm_small_ex(const float* A, const float* A2, int lda, int M, int K, const half_t* Whi, const half_t* Wlo, int N, int Kpad,
+                         const float* bias, int act, const float* R, int ldr, float* C, int ldc, int npass, float* ws, size_t ws_bytes,
+                         hipStream_t s);
 void gemm_small_set(int target_blocks, int max_ksplit);
 void gemm_small_set_stages(int n);
 void glinear_set_small_max_tiles(int t);

@@ -17,6 +17,7 @@ namespace ovm {
 
 struct SmallGemmParams {
   const float* A; int lda;
+  const float* A2;                        // optional second term of the A operand (x = A + A2), same layout
   const half_t* Whi; const half_t* Wlo;   // [Npad][Kpad], Npad % 128 == 0, Kpad % 64 == 0, zero padded
   int M, N, K, Kpad;
   const float* bias; int act; const float* R; int ldr; float* C; int ldc;
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(256) void gemm_f32a_kernel(const SmallGemmParams p)
   const int row = tid >> 2, q = tid & 3;
   int am = m0 + row; if (am > p.M - 1) am = p.M - 1;
   const float* ap = p.A + (size_t)am * p.lda + q * 16;
+  const float* ap2 = p.A2 ? p.A2 + (size_t)am * p.lda + q * 16 : nullptr;
   // weights: one-pass [Npad][Kpad]; split mode the interleaved image [Npad][Kpad/32][hi 32 | lo 32] (k0 is a multiple of 64, q*16 of
   // 16: the 16 halves a thread moves never straddle a 32-group)
   const half_t* whp = (NPASS == 3) ? p.Whi + (size_t)(n0 + row) * 2 * p.Kpad + (q >> 1) * 64 + (q & 1) * 16
@@ -80,6 +82,13 @@ __global__ __launch_bounds__(256) void gemm_f32a_kernel(const SmallGemmParams p)
     r.a1 = (kq + 4 < p.K) ? *(const float4*)(ap + k0 + 4) : z4;
     r.a2 = (kq + 8 < p.K) ? *(const float4*)(ap + k0 + 8) : z4;
     r.a3 = (kq + 12 < p.K) ? *(const float4*)(ap + k0 + 12) : z4;
+    if (ap2) {                                                // wave-uniform
+      auto add4 = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+      if (kq < p.K) add4(r.a0, *(const float4*)(ap2 + k0));
+      if (kq + 4 < p.K) add4(r.a1, *(const float4*)(ap2 + k0 + 4));
+      if (kq + 8 < p.K) add4(r.a2, *(const float4*)(ap2 + k0 + 8));
+      if (kq + 12 < p.K) add4(r.a3, *(const float4*)(ap2 + k0 + 12));
+    }
     r.wh0 = *(const uint4*)(whp + k0 * wkm); r.wh1 = *(const uint4*)(whp + k0 * wkm + 8);
     if (NPASS == 3) { r.wl0 = *(const uint4*)(wlp + k0 * wkm); r.wl1 = *(const uint4*)(wlp + k0 * wkm + 8); }
   };
@@ -244,8 +253,14 @@ bool gemm_small_supported(const float* A, int lda, int K) {
 
 int launch_gemm_small(const float* A, int lda, int M, int K, const half_t* Whi, const half_t* Wlo, int N, int Kpad, const float* bias, int act,
                       const float* R, int ldr, float* C, int ldc, int npass, hipStream_t s) {
+  return launch_gemm_small_ex(A, nullptr, lda, M, K, Whi, Wlo, N, Kpad, bias, act, R, ldr, C, ldc, npass, nullptr, 0, s);
+}
+
+int launch_gemm_small_ex(const float* A, const float* A2, int lda, int M, int K, const half_t* Whi, const half_t* Wlo, int N, int Kpad,
+                         const float* bias, int act, const float* R, int ldr, float* C, int ldc, int npass, float* ws, size_t ws_bytes,
+                         hipStream_t s) {
   SmallGemmParams p;
-  p.A = A; p.lda = lda; p.Whi = Whi; p.Wlo = Wlo; p.M = M; p.N = N; p.K = K; p.Kpad = Kpad;
+  p.A = A; p.A2 = A2; p.lda = lda; p.Whi = Whi; p.Wlo = Wlo; p.M = M; p.N = N; p.K = K; p.Kpad = Kpad;
   p.bias = bias; p.act = act; p.R = R; p.ldr = ldr; p.C = C; p.ldc = ldc;
   p.tiles_m = (M + 63) / 64; p.tiles_n = (N + 63) / 64;
   const int tiles = p.tiles_m * p.tiles_n;
@@ -265,12 +280,15 @@ int launch_gemm_small(const float* A, int lda, int M, int K, const half_t* Whi, 
              (!bias || (((uintptr_t)bias & 15) == 0));
   if (ksplit > 1) {
     const size_t need = (size_t)ksplit * M * p.ldp * sizeof(float);
-    if (g_ws.cap < need) {
+    if (ws) {
+      if (ws_bytes < need) return OVM_ERR_CAPACITY;
+      p.partial = ws;
+    } else if (g_ws.cap < need) {
       if (g_ws.p) { (void)hipDeviceSynchronize(); (void)hipFree(g_ws.p); }
       g_ws.cap = need + need / 2 + (1 << 20);
       if (hipMalloc((void**)&g_ws.p, g_ws.cap) != hipSuccess) { g_ws.p = nullptr; g_ws.cap = 0; return OVM_ERR_HIP; }
     }
-    p.partial = g_ws.p;
+    if (!ws) p.partial = g_ws.p;
   }
   const dim3 grid((unsigned)(tiles * ksplit));
   if (g_stages == 2) {

@@ -44,6 +44,17 @@ class OvmImage(C.Structure):
                 ("orig_height", C.c_int32), ("orig_width", C.c_int32), ("K", C.c_float * 9)]
 
 
+class OvmGdinoConfig(C.Structure):
+    _fields_ = [
+        ("d_model", C.c_int32), ("enc_layers", C.c_int32), ("dec_layers", C.c_int32), ("heads", C.c_int32), ("ffn_dim", C.c_int32),
+        ("n_levels", C.c_int32), ("n_points", C.c_int32), ("num_queries", C.c_int32), ("max_text_len", C.c_int32),
+        ("pe_temperature", C.c_float), ("eps", C.c_float), ("bert_heads", C.c_int32),
+        ("swin_embed", C.c_int32), ("swin_depths", C.c_int32 * 4), ("swin_heads", C.c_int32 * 4), ("swin_window", C.c_int32),
+        ("pixel_mean", C.c_float * 3), ("pixel_std", C.c_float * 3), ("flip_channels", C.c_int32), ("precision", C.c_int32),
+        ("use_graphs", C.c_int32), ("max_plans", C.c_int32),
+    ]
+
+
 EXPORTS = [
     "ovm_create", "ovm_destroy", "ovm_last_error", "ovm_version", "ovm_backbone_forward", "ovm_cube_forward",
     "ovm_rpn_box_forward", "ovm_gather_records", "ovm_gather_counts", "ovm_host_interp_pos_embed", "ovm_host_shard_range",
@@ -52,6 +63,8 @@ EXPORTS = [
     "ovm_comm_unique_id", "ovm_comm_init", "ovm_comm_destroy", "ovm_tune_set", "ovm_gdino_postprocess", "ovm_box3d_iou", "ovm_host_pil_bilinear_coeffs", "ovm_resize_bilinear_u8",
     "ovm_g_pack_weight", "ovm_g_linear", "ovm_g_layernorm", "ovm_g_bmm", "ovm_g_bmm2", "ovm_g_softmax", "ovm_g_softmax2", "ovm_g_eltwise", "ovm_g_gather_rows",
     "ovm_g_groupnorm", "ovm_g_msdeform", "ovm_g_sine_embed", "ovm_g_normalize_image", "ovm_g_topk", "ovm_g_rowmax",
+    "ovm_gdino_create", "ovm_gdino_destroy", "ovm_gdino_last_error", "ovm_gdino_forward", "ovm_gdino_detect", "ovm_gdino_set_force_topk",
+    "ovm_gdino_debug_copy",
 ]
 PROF_NAMES = ("attn", "qkv", "proj", "fc1", "fc2", "ln")
 
@@ -117,8 +130,17 @@ def load() -> C.CDLL:
     lib.ovm_g_topk.argtypes = [vp, i32, i32, vp, vp]
     lib.ovm_g_rowmax.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.ovm_gdino_postprocess.argtypes = [vp, i32, i32, vp, C.POINTER(i32), i32, i32, i32, f32, f32, vp, vp, vp, vp, vp]
+    lib.ovm_gdino_create.argtypes = [C.POINTER(OvmGdinoConfig), C.POINTER(OvmTensor), i32, i32, C.POINTER(vp)]
+    lib.ovm_gdino_destroy.argtypes = [vp]
+    lib.ovm_gdino_last_error.argtypes = [vp]
+    lib.ovm_gdino_last_error.restype = C.c_char_p
+    lib.ovm_gdino_forward.argtypes = [vp, C.POINTER(OvmImage), C.POINTER(i32), i32, C.POINTER(i32), vp, vp, vp]
+    lib.ovm_gdino_detect.argtypes = [vp, C.POINTER(OvmImage), C.POINTER(i32), i32, C.POINTER(i32), i32, f32, f32, vp, vp, vp, vp, vp]
+    lib.ovm_gdino_set_force_topk.argtypes = [vp, vp]
+    lib.ovm_gdino_debug_copy.argtypes = [vp, C.c_char_p, vp, i64, vp]
+    lib.ovm_gdino_debug_copy.restype = i64
     for name in EXPORTS:
-        if name not in ("ovm_last_error", "ovm_version", "ovm_debug_copy"):
+        if name not in ("ovm_last_error", "ovm_version", "ovm_debug_copy", "ovm_gdino_last_error", "ovm_gdino_debug_copy"):
             getattr(lib, name).restype = i32
     # experiment knobs, e.g. OVM_TUNE="gemm_bm=256,attn_tail=0"
     for kv in filter(None, os.environ.get("OVM_TUNE", "").split(",")):
