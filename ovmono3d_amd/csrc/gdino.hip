@@ -478,7 +478,7 @@ int build_plan(OvmGdino* g, int H, int W, const std::vector<int>& ids, const std
     return OVM_ERR_SHAPE;
   }
   RCHECK(g, pal(g, pl, &pl->img, (size_t)H * W * 3));
-  pl->topk_N = 1; while (pl->topk_N < std::max(S, 1024)) pl->topk_N <<= 1;
+  pl->topk_N = 2048; while (pl->topk_N < S) pl->topk_N <<= 1;      // the bitonic sort's minimum length is one 2048-key tile
   RCHECK(g, pal(g, pl, &pl->topk_keys, (size_t)pl->topk_N));
   RCHECK(g, pal(g, pl, &pl->out_logits, (size_t)c.num_queries * c.max_text_len));
   RCHECK(g, pal(g, pl, &pl->out_boxes, (size_t)c.num_queries * 4));
@@ -516,7 +516,7 @@ struct Run {
     const size_t bytes = rows * b.ld * sizeof(half_t);
     b.hi = (half_t*)alloc(bytes);
     b.lo = g->npass == 3 ? (half_t*)alloc(bytes) : nullptr;
-    if (b.ld != K && !dry) {
+    if (b.ld != K && go()) {
       if (hipMemsetAsync(b.hi, 0, bytes, s) != hipSuccess) fail(OVM_ERR_HIP, "memset");
       if (b.lo && hipMemsetAsync(b.lo, 0, bytes, s) != hipSuccess) fail(OVM_ERR_HIP, "memset");
     }
@@ -529,7 +529,8 @@ struct Run {
   void tap(const char* name, const void* p, int64_t n) { if (!dry) pl->taps[name] = {p, n}; }
 
   // ---- op wrappers (all skip the launch in a dry pass) ----
-  void rowop(RowOpParams p) { if (!dry) chk(launch_rowop(p, s), "rowop"); }
+  bool go() const { return !dry && rc == OVM_OK; }      // after a failure nothing further is launched (later kernels would read its garbage)
+  void rowop(RowOpParams p) { if (go()) chk(launch_rowop(p, s), "rowop"); }
 
   // big GEMM on the LDS-DMA kernels of gemm.hpp: A split fp16 [M][lda]
   GemmParams gp(const SplitBuf& A, int M, const Lin& W) {
@@ -538,11 +539,11 @@ struct Run {
     p.ws_slot = 1; p.part_ws = pl->gemm_ws; p.part_cap = pl->gemm_ws_cap;
     return p;
   }
-  void gemm(const GemmParams& p, int epi) { if (!dry) chk(launch_gemm(p, g->npass, epi, A_ROWMAJOR, s), "gemm"); }
+  void gemm(const GemmParams& p, int epi) { if (go()) chk(launch_gemm(p, g->npass, epi, A_ROWMAJOR, s), "gemm"); }
 
   // small / mid GEMM reading fp32 activations directly (gemm_small.hip): y = act((A + A2) W^T + b) (+ R)
   void lin(const float* A, const float* A2, int lda, int M, const Lin& W, int act, const float* R, int ldr, float* C, int ldc) {
-    if (dry || M <= 0) return;
+    if (!go() || M <= 0) return;
     if (!gemm_small_supported(A, lda, W.K) || (A2 && (((uintptr_t)A2) & 15))) { fail(OVM_ERR_SHAPE, "lin: unaligned fp32 operand"); return; }
     chk(launch_gemm_small_ex(A, A2, lda, M, W.K, W.hi, W.lo, W.N, W.Kpad, W.bias, act, R, ldr, C, ldc, g->npass, pl->gemm_ws, pl->gemm_ws_cap, s),
         "lin");
@@ -553,7 +554,7 @@ struct Run {
     if (sp) { p.hi = sp->hi; p.lo = sp->lo; p.ldh = sp->ld; }
     rowop(p);
   }
-  void attn(AttnF32Params p) { if (!dry) chk(launch_attn_f32(p, s), "attn_f32"); }
+  void attn(AttnF32Params p) { if (go()) chk(launch_attn_f32(p, s), "attn_f32"); }
 };
 
 inline int kpad64(int k) { return (k + 63) / 64 * 64; }
@@ -572,7 +573,7 @@ void mha_core(Run& r, const float* q, int ldq, const float* k, int ldk, const fl
 
 void deform(Run& r, const MsdaW& w, const float* value, int ldv, const float* ow, int ldow, const float* ref, int ldref, int mode, int Q,
             float* out, SplitBuf* osp) {
-  if (r.dry) return;
+  if (!r.go()) return;
   const OvmGdinoConfig& c = r.g->cfg;
   MsDeformParams p; memset(&p, 0, sizeof(p));
   p.value = value; p.ldv = ldv; p.ow = ow; p.ldow = ldow; p.ref = ref; p.ldref = ldref; p.mode = mode;
@@ -594,7 +595,7 @@ int forward_impl(Run& r) {
   // =============================== text: BERT + projection ===============================
   const int BD = g->bertD, BH = c.bert_heads;
   float* tx = r.f32((size_t)T * BD);
-  if (!dry) r.chk(launch_bert_embed(g->word, g->posemb, g->typemb, pl->d_ids, pl->d_pids, T, BD, g->emb_ln.g, g->emb_ln.b, 1e-12f, tx, s), "bert_embed");
+  if (r.go()) r.chk(launch_bert_embed(g->word, g->posemb, g->typemb, pl->d_ids, pl->d_pids, T, BD, g->emb_ln.g, g->emb_ln.b, 1e-12f, tx, s), "bert_embed");
   {
     float* qkv = r.f32((size_t)T * 3 * BD);
     float* ctx = r.f32((size_t)T * BD);
@@ -611,9 +612,10 @@ int forward_impl(Run& r) {
     }
   }
   r.tap("bert_out", tx, (int64_t)T * BD);
-  float* text = r.f32((size_t)T * D);
-  r.lin(tx, nullptr, BD, T, g->text_proj, 0, nullptr, 0, text, D);
-  r.tap("text_features", text, (int64_t)T * D);
+  float* text0 = r.f32((size_t)T * D);
+  r.lin(tx, nullptr, BD, T, g->text_proj, 0, nullptr, 0, text0, D);
+  r.tap("text_features", text0, (int64_t)T * D);
+  float* text = r.f32((size_t)T * D);                     // encoder output (the input above stays intact for the debug tap)
 
   // =============================== image: Swin backbone ===============================
   const int ws = c.swin_window, ws2 = ws * ws;
@@ -698,7 +700,8 @@ int forward_impl(Run& r) {
   }
 
   // =============================== neck: input projections + GroupNorm ===============================
-  float* vis = r.f32((size_t)S * D);
+  float* vis0 = r.f32((size_t)S * D);
+  float* vis = r.f32((size_t)S * D);                      // encoder state / output
   {
     const size_t mk = r.mark();
     for (int l = 0; l < c.n_levels; ++l) {
@@ -721,7 +724,7 @@ int forward_impl(Run& r) {
         GemmParams q = r.gp(a, n, g->inproj[l].w); q.C = y; q.ldc = D;
         r.gemm(q, EPI_STORE);
       }
-      if (!dry) r.chk(ovm_g_groupnorm(y, 1, n, D, 32, g->inproj[l].gn.g, g->inproj[l].gn.b, 1e-5f, vis + (size_t)pl->lstart[l] * D, s), "groupnorm");
+      if (r.go()) r.chk(ovm_g_groupnorm(y, 1, n, D, 32, g->inproj[l].gn.g, g->inproj[l].gn.b, 1e-5f, vis0 + (size_t)pl->lstart[l] * D, s), "groupnorm");
     }
     r.release(mk);
   }
@@ -750,13 +753,15 @@ int forward_impl(Run& r) {
     SplitBuf dsp = r.split((size_t)S, D);
     float* pre = r.f32((size_t)S * D);
     SplitBuf ff = r.split((size_t)S, c.ffn_dim);
+    const float* vis_in = vis0; const float* text_in = text0;
     for (auto& ly : g->enc) {
       // ---- fusion layer (bi-directional image <-> text attention)
-      r.ln(vis, S, D, ly.lnv, eps, nullptr, v, &vsp);
-      r.ln(text, T, D, ly.lnt, eps, nullptr, t);
+      r.ln(vis_in, S, D, ly.lnv, eps, nullptr, v, &vsp);
+      r.ln(text_in, T, D, ly.lnt, eps, nullptr, t);
+      vis_in = vis; text_in = text;
       { GemmParams q = r.gp(vsp, S, ly.vqv); q.C = qvv; q.ldc = 2 * E; r.gemm(q, EPI_STORE); }
       r.lin(t, nullptr, D, T, ly.tkv, 0, nullptr, 0, tkv, 2 * E);
-      if (!dry) {
+      if (r.go()) {
         BiAttnParams b; memset(&b, 0, sizeof(b));
         b.qv = qvv; b.ldq = 2 * E; b.kt = tkv; b.ldk = 2 * E; b.vv = qvv + E; b.ldvv = 2 * E; b.vt = tkv + E; b.ldvt = 2 * E;
         b.S = S; b.T = T; b.H = HF; b.dh = dhf; b.scale = 1.0f / sqrtf((float)dhf);
@@ -792,6 +797,7 @@ int forward_impl(Run& r) {
     }
     r.release(mk);
   }
+  r.tap("source_flatten", vis0, (int64_t)S * D);
   r.tap("enc_vision", vis, (int64_t)S * D);
   r.tap("enc_text", text, (int64_t)T * D);
 
@@ -811,19 +817,19 @@ int forward_impl(Run& r) {
     float* oq = r.f32((size_t)S * D);
     r.ln(oq0, S, D, g->enc_output_ln, eps, nullptr, oq, &oqs);
     float* cls = r.f32((size_t)S * T);
-    if (!dry) r.chk(ovm_g_bmm(oq, text, cls, 1, S, T, D, D, D, T, 0, 0, 0, 1, 1.0f, s), "bmm cls");
+    if (r.go()) r.chk(ovm_g_bmm(oq, text, cls, 1, S, T, D, D, D, T, 0, 0, 0, 1, 1.0f, s), "bmm cls");
     float* mx = r.f32((size_t)S);
-    if (!dry) r.chk(ovm_g_rowmax(cls, S, T, T, mx, s), "rowmax");
+    if (r.go()) r.chk(ovm_g_rowmax(cls, S, T, T, mx, s), "rowmax");
     const int* sel = topk;
     if (g->force_topk) sel = g->force_topk;
-    else if (!dry) r.chk(launch_topk_keys(mx, S, Q, topk, pl->topk_keys, pl->topk_N, s), "topk");
+    else if (r.go()) r.chk(launch_topk_keys(mx, S, Q, topk, pl->topk_keys, pl->topk_N, s), "topk");
     SplitBuf h1 = r.split((size_t)S, D), h2 = r.split((size_t)S, D);
     { GemmParams q = r.gp(oqs, S, g->enc_bbox[0]); q.Ohi = h1.hi; q.Olo = h1.lo; q.ldo = h1.ld; q.relu = 1; r.gemm(q, EPI_STORE); }
     { GemmParams q = r.gp(h1, S, g->enc_bbox[1]); q.Ohi = h2.hi; q.Olo = h2.lo; q.ldo = h2.ld; q.relu = 1; r.gemm(q, EPI_STORE); }
     float* coord = r.f32((size_t)S * 4);
     { GemmParams q = r.gp(h2, S, g->enc_bbox[2]); q.C = coord; q.ldc = 4; r.gemm(q, EPI_STORE); }
-    if (!dry) r.chk(launch_select_ref(coord, 4, pl->prop_logit, sel, Q, ref, s), "select_ref");
-    if (!dry && g->force_topk) GCHECK(g, hipMemcpyAsync(topk, g->force_topk, sizeof(int) * Q, hipMemcpyDeviceToDevice, s));
+    if (r.go()) r.chk(launch_select_ref(coord, 4, pl->prop_logit, sel, Q, ref, s), "select_ref");
+    if (r.go() && g->force_topk) GCHECK(g, hipMemcpyAsync(topk, g->force_topk, sizeof(int) * Q, hipMemcpyDeviceToDevice, s));
     r.release(mk);
   }
   r.tap("topk", topk, Q);
@@ -847,7 +853,7 @@ int forward_impl(Run& r) {
     }
     float* val_all = r.f32((size_t)S * NL * D);
     { GemmParams q = r.gp(vsp, S, g->dec_value); q.C = val_all; q.ldc = NL * D; r.gemm(q, EPI_STORE); }
-    if (!dry) GCHECK(g, hipMemcpyAsync(hs, g->tgt, sizeof(float) * (size_t)Q * D, hipMemcpyDeviceToDevice, s));
+    if (r.go()) GCHECK(g, hipMemcpyAsync(hs, g->tgt, sizeof(float) * (size_t)Q * D, hipMemcpyDeviceToDevice, s));
     float* sine = r.f32((size_t)Q * 2 * D);
     float* qh = r.f32((size_t)Q * D); float* qpos = r.f32((size_t)Q * D);
     float* qk = r.f32((size_t)Q * 2 * D); float* vq = r.f32((size_t)Q * D); float* ctx = r.f32((size_t)Q * D);
@@ -861,7 +867,7 @@ int forward_impl(Run& r) {
     for (int i = 0; i < NL; ++i) {
       DecLayer& ly = g->dec[i];
       float* rf = refs[cur];
-      if (!dry) r.chk(ovm_g_sine_embed(rf, Q, 4, D / 2, 10000.0f, sine, s), "sine_embed");
+      if (r.go()) r.chk(ovm_g_sine_embed(rf, Q, 4, D / 2, 10000.0f, sine, s), "sine_embed");
       r.lin(sine, nullptr, 2 * D, Q, g->ref_head[0], 1, nullptr, 0, qh, D);
       r.lin(qh, nullptr, D, Q, g->ref_head[1], 0, nullptr, 0, qpos, D);
       // self-attention
@@ -884,28 +890,28 @@ int forward_impl(Run& r) {
       r.lin(hs, nullptr, D, Q, ly.fc1, 1, nullptr, 0, ffb, c.ffn_dim);
       r.lin(ffb, nullptr, c.ffn_dim, Q, ly.fc2, 0, hs, D, pre, D);
       r.ln(pre, Q, D, ly.ln4, eps, nullptr, hs);
-      if (i == NL - 1) { if (!dry) GCHECK(g, hipMemcpyAsync(last_ref, rf, sizeof(float) * (size_t)Q * 4, hipMemcpyDeviceToDevice, s)); }
+      if (i == NL - 1) { if (r.go()) GCHECK(g, hipMemcpyAsync(last_ref, rf, sizeof(float) * (size_t)Q * 4, hipMemcpyDeviceToDevice, s)); }
       r.tap(("dec_hs" + std::to_string(i)).c_str(), hs, (int64_t)Q * D);
       // iterative box refinement (the update after the last layer is unused)
       if (i + 1 < NL) {
         r.lin(hs, nullptr, D, Q, g->bbox[i][0], 1, nullptr, 0, b1, D);
         r.lin(b1, nullptr, D, Q, g->bbox[i][1], 1, nullptr, 0, b2, D);
         r.lin(b2, nullptr, D, Q, g->bbox[i][2], 0, nullptr, 0, delta, 4);
-        if (!dry) r.chk(launch_box_refine(delta, 4, rf, 1e-5f, refs[cur ^ 1], Q, s), "box_refine");
+        if (r.go()) r.chk(launch_box_refine(delta, 4, rf, 1e-5f, refs[cur ^ 1], Q, s), "box_refine");
         cur ^= 1;
       }
     }
     // ---- heads on the normalised last hidden state
     r.ln(hs, Q, D, g->dec_ln, eps, nullptr, hn);
     float* lt = r.f32((size_t)Q * T);
-    if (!dry) {
+    if (r.go()) {
       r.chk(ovm_g_bmm(hn, text, lt, 1, Q, T, D, D, D, T, 0, 0, 0, 1, 1.0f, s), "bmm logits");
       r.chk(launch_pad_logits(lt, T, Q, T, pl->out_logits, c.max_text_len, s), "pad_logits");
     }
     r.lin(hn, nullptr, D, Q, g->bbox[NL - 1][0], 1, nullptr, 0, b1, D);
     r.lin(b1, nullptr, D, Q, g->bbox[NL - 1][1], 1, nullptr, 0, b2, D);
     r.lin(b2, nullptr, D, Q, g->bbox[NL - 1][2], 0, nullptr, 0, delta, 4);
-    if (!dry) r.chk(launch_box_refine(delta, 4, last_ref, 1e-5f, pl->out_boxes, Q, s), "box_refine");
+    if (r.go()) r.chk(launch_box_refine(delta, 4, last_ref, 1e-5f, pl->out_boxes, Q, s), "box_refine");
     r.release(mk);
   }
   return r.rc;

@@ -70,6 +70,7 @@ def test_engine_matches_python_sequenced_path_small(device):
     lg, bx, aux = net.forward(x, H, W, torch.tensor(ids), return_aux=True)
     T = len(ids)
     assert_close(eng.debug("text_features", (T, 64)), aux["text_features"], 2e-5, "text features")
+    assert_close(eng.debug("source_flatten", tuple(aux["source_flatten"].shape)), aux["source_flatten"], 5e-5, "projected image features")
     assert_close(eng.debug("enc_vision", tuple(aux["enc_vision"].shape)), aux["enc_vision"], 5e-5, "encoder vision")
     assert_close(eng.debug("enc_text", (T, 64)), aux["enc_text"], 5e-5, "encoder text")
     assert sorted(eng.debug("topk", (30,), torch.int32).cpu().tolist()) == sorted(aux["topk"].cpu().tolist())
