@@ -133,23 +133,34 @@ def convert_upstream_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.
 class NativeGroundingDino:
     """callable(image_u8_chw, caption) -> raw network outputs + token ids, as ROIHeads3DGDINO.forward expects.
 
-    The network is ~1,300 short kernels sequenced from Python; issuing them costs more host time than they run for. The
-    second time an (image size, caption) pair is seen the whole forward (image normalisation included) is captured into a
-    HIP graph on a static input buffer and replayed from then on; ``use_graphs=False`` keeps the eager path."""
+    Default (``engine=True``): the network runs inside libovm3d (``ovm_gdino_forward``, ``gdino/engine.py``): C++ sequencing,
+    fused kernels, one plan + HIP graph per (image size, caption), scratch owned by the plan. ``engine=False`` keeps the
+    round-1 path - generic ``ovm_g_*`` ops sequenced from Python (``gdino/model.py``), captured into a HIP graph the second
+    time an (image size, caption) pair is seen - as an independent cross-check of the engine; its process-global scratch can be
+    re-sized under a captured graph, so it should not be used with ``use_graphs`` on inputs of varying size."""
 
     MAX_GRAPHS = 16
 
     def __init__(self, device: torch.device, state_dict: Dict[str, torch.Tensor], tokenizer, pixel_mean, pixel_std,
-                 cfg: GDinoConfig = GDinoConfig(), precision: int = 3, use_graphs: bool = True):
+                 cfg: GDinoConfig = GDinoConfig(), precision: int = 3, use_graphs: bool = True, engine: bool = True):
         if "model.text_projection.weight" not in state_dict:
             state_dict = convert_upstream_state_dict(state_dict)
-        self.ops = Ops(device, precision)
-        self.net = GroundingDinoNative(self.ops, state_dict, cfg)
         self.tok, self.mean, self.std = tokenizer, list(pixel_mean), list(pixel_std)
         self.use_graphs = use_graphs
+        self.engine = None
+        self._tok_cache: Dict[str, tuple] = {}
+        if engine:
+            from .engine import GdinoEngine
+            # the reference hands GroundingDINO images[0][[2,1,0]]: the normalised, unpadded image with channels flipped (:146)
+            self.engine = GdinoEngine(device, state_dict, cfg, pixel_mean=self.mean, pixel_std=self.std, flip_channels=True,
+                                      precision=precision, use_graphs=use_graphs)
+            self.dev = device
+            return
+        self.ops = Ops(device, precision)
+        self.dev = device
+        self.net = GroundingDinoNative(self.ops, state_dict, cfg)
         self._graphs: Dict[tuple, tuple] = {}
         self._seen: Dict[tuple, int] = {}
-        self._tok_cache: Dict[str, tuple] = {}
 
     def _tokens(self, caption: str):
         t = self._tok_cache.get(caption)
@@ -172,8 +183,11 @@ class NativeGroundingDino:
         return self.net.forward(x, d.height, d.width, ids_t)
 
     def __call__(self, image_u8_chw: torch.Tensor, caption: str) -> Dict:
-        im = image_u8_chw.to(self.ops.dev)
+        im = image_u8_chw.to(self.dev)
         ids, phrase_ids, ids_t = self._tokens(caption)
+        if self.engine is not None:
+            logits, boxes = self.engine.forward(im, ids)
+            return {"pred_logits": logits, "pred_boxes": boxes, "input_ids": ids, "phrase_ids": phrase_ids}
         key = (tuple(im.shape), tuple(ids))
         entry = self._graphs.get(key) if self.use_graphs else None
         if entry is None and self.use_graphs:

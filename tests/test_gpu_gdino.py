@@ -273,8 +273,9 @@ def test_full_size_gdino_swinb_matches_hf(device):
 
 
 def test_detector_graph_replay_matches_eager(device):
-    """NativeGroundingDino captures the forward into a HIP graph on the second sight of an (image size, caption) pair; the
-    replay on new pixels must equal the eager forward on those pixels bit for bit."""
+    """The Python-sequenced cross-check path (engine=False) captures its forward into a HIP graph on the second sight of an
+    (image size, caption) pair; the replay on new pixels must equal the eager forward on those pixels bit for bit. (The product
+    path is the C++ engine: tests/test_gpu_gdino_engine.py.)"""
     from ovmono3d_amd.gdino.detector import HashTokenizer, NativeGroundingDino
     from ovmono3d_amd.gdino.model import GDinoConfig
     hf, cfg = _small_hf_gdino()
@@ -286,8 +287,8 @@ def test_detector_graph_replay_matches_eager(device):
     class Tok(HashTokenizer):
         def _id(self, w):
             return super()._id(w) % 1900 + 50 if w not in (".", "?") else super()._id(w)
-    eager = NativeGroundingDino(device, sd, Tok(), mean, std, cfg=ncfg, use_graphs=False)
-    graphed = NativeGroundingDino(device, sd, Tok(), mean, std, cfg=ncfg, use_graphs=True)
+    eager = NativeGroundingDino(device, sd, Tok(), mean, std, cfg=ncfg, use_graphs=False, engine=False)
+    graphed = NativeGroundingDino(device, sd, Tok(), mean, std, cfg=ncfg, use_graphs=True, engine=False)
     g = torch.Generator().manual_seed(3)
     caption = "chair . dining table ."
     for i in range(4):
