@@ -278,6 +278,7 @@ int ovm_g_topk(const float* scores, int32_t n, int32_t k, int32_t* out_idx, ovm_
  * library). Defaults are the measured best; none changes results beyond fp32 summation order.
  *   gemm_bm 0|128|256, gemm_stages 0 (auto: wave-specialised kernel up to 512 tiles, symmetric 2-slot kernel above) |2|3|5|6,
  *   gemm_splitk 0|1, gemm_tail 0|1 (leftover rows as dot-product workgroups), attn_waves 0 (auto)|4|8, attn_lds_pad bytes,
+ *   gemm256 0|1 (256 x 256 two-wave-group kernel for qkv / fc1), op_gemm256 n (ovm_op_gemm on that kernel, n = split-K hint),
  *   attn_tail 0|1, glin_small_max_tiles (-1 = heuristic), glin_target_blocks, glin_max_ksplit, glin_stages 1|2, gbmm_tiled 0|1 */
 int ovm_tune_set(const char* key, int32_t value);
 

@@ -105,6 +105,16 @@ int dalloc(OvmHandle* h, Tp** p, size_t count, bool zero = false) {
   return OVM_OK;
 }
 
+// interleaved split image [rows][K/32][hi 32 | lo 32] (f16x3 mode; plain fp16 rows in one-pass mode): the A-operand layout of the
+// 256 x 256 GEMM (one 128-byte LDS-DMA line per row and k-group holds both parts)
+int salloc_il(OvmHandle* h, Split* s, size_t count) {
+  if (h->npass != 3) { s->lo = nullptr; return dalloc(h, &s->hi, count); }
+  int r = dalloc(h, &s->hi, 2 * count);
+  if (r) return r;
+  s->lo = s->hi + 32;
+  return OVM_OK;
+}
+
 int salloc(OvmHandle* h, Split* s, size_t count, bool zero = false) {
   int r = dalloc(h, &s->hi, count, zero);
   if (r) return r;
@@ -265,8 +275,14 @@ struct ProfScope {
   ~ProfScope() { if (stop) (void)hipEventRecord(stop, s); }
 };
 
+int g_use_gemm256 = 1;     // ovm_tune_set("gemm256", 0 | 1)
+
 int gemm(OvmHandle* h, const GemmParams& p, int epi, int amode, hipStream_t s, int cat = -1) {
   ProfScope ps(h, cat, s);
+  // the large block contractions (qkv, fc1: >= 2048 rows and >= 3072 columns -> at least 192 tiles of 256 x 256) go to the
+  // two-wave-group 256 x 256 kernel; everything else keeps the 128 x 128 kernels
+  if (g_use_gemm256 && amode == A_ROWMAJOR && p.M >= 2048 && p.N >= 3072 && gemm256_supported(p, h->npass))
+    return launch_gemm256(p, epi, 1, s);
   return launch_gemm(p, h->npass, epi, amode, s);
 }
 
@@ -291,6 +307,8 @@ void fill_meta(OvmHandle* h, const OvmImage* images, int B) {
 }
 
 }  // namespace
+
+namespace ovm { void set_use_gemm256(int v) { g_use_gemm256 = v; } }
 
 extern "C" {
 
@@ -459,9 +477,9 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
   const size_t MT = (size_t)B * T, MP = (size_t)B * G2;
   if ((r = dalloc(h, &h->X, MT * D))) return r;
   if ((r = salloc(h, &h->PA, MP * h->Kpe))) return r;
-  if ((r = salloc(h, &h->HN, MT * D))) return r;
-  if ((r = salloc(h, &h->AO, MT * D))) return r;
-  if ((r = salloc(h, &h->F1, MT * 4 * D))) return r;
+  if ((r = salloc_il(h, &h->HN, MT * D))) return r;
+  if ((r = salloc_il(h, &h->AO, MT * D))) return r;
+  if ((r = salloc_il(h, &h->F1, MT * 4 * D))) return r;
   if ((r = salloc(h, &h->Q, MT * D))) return r;
   if ((r = salloc(h, &h->Kx, MT * D))) return r;
   if ((r = salloc(h, &h->Vt, (size_t)B * D * h->Tpad, true))) return r;
@@ -559,10 +577,11 @@ int ovm_backbone_forward(OvmHandle* h, const OvmImage* images, int32_t B, const 
   const int M = B * T;
   for (int l = 0; l < L; ++l) {
     const Layer& y = h->layers[l];
-    LnOut o; memset(&o, 0, sizeof(o)); o.hi = h->HN.hi; o.lo = h->HN.lo; o.ld = D;
+    const int il = h->npass == 3 ? 1 : 0, am = il ? 2 : 1;    // activations of the blocks: interleaved split images in f16x3 mode
+    LnOut o; memset(&o, 0, sizeof(o)); o.hi = h->HN.hi; o.lo = h->HN.lo; o.ld = am * D; o.il = il;
     { ProfScope ps(h, OVM_PROF_LN, s); KCHECK(h, launch_ln_rows(h->X, D, M, D, y.ln1g, y.ln1b, 1e-6f, o, s)); }
     {
-      GemmParams p = gp_base(h->HN, D, y.qkv, M);
+      GemmParams p = gp_base(h->HN, am * D, y.qkv, M); p.a_il = il;
       p.Qhi = h->Q.hi; p.Qlo = h->Q.lo; p.Khi = h->Kx.hi; p.Klo = h->Kx.lo; p.Vhi = h->Vt.hi; p.Vlo = h->Vt.lo;
       p.T = T; p.Tpad = h->Tpad; p.heads = c.heads; p.qscale = kQScale;
       KCHECK(h, gemm(h, p, EPI_QKV, A_ROWMAJOR, s, OVM_PROF_QKV));
@@ -570,23 +589,23 @@ int ovm_backbone_forward(OvmHandle* h, const OvmImage* images, int32_t B, const 
     {
       AttnParams a; memset(&a, 0, sizeof(a));
       a.Qhi = h->Q.hi; a.Qlo = h->Q.lo; a.Khi = h->Kx.hi; a.Klo = h->Kx.lo; a.Vhi = h->Vt.hi; a.Vlo = h->Vt.lo;
-      a.Ohi = h->AO.hi; a.Olo = h->AO.lo; a.ldo = D; a.B = B; a.heads = c.heads; a.T = T; a.Tpad = h->Tpad;
+      a.Ohi = h->AO.hi; a.Olo = h->AO.lo; a.ldo = am * D; a.o_il = il; a.B = B; a.heads = c.heads; a.T = T; a.Tpad = h->Tpad;
       a.corun = h->corun ? 1 : 0;
       { ProfScope ps(h, OVM_PROF_ATTN, s); KCHECK(h, launch_attention(a, h->npass, s)); }
     }
     {
-      GemmParams p = gp_base(h->AO, D, y.proj, M);
+      GemmParams p = gp_base(h->AO, am * D, y.proj, M); p.a_il = il;
       p.gamma = y.ls1; p.X = h->X; p.ldx = D;
       KCHECK(h, gemm(h, p, EPI_RESID, A_ROWMAJOR, s, OVM_PROF_PROJ));
     }
     { ProfScope ps(h, OVM_PROF_LN, s); KCHECK(h, launch_ln_rows(h->X, D, M, D, y.ln2g, y.ln2b, 1e-6f, o, s)); }
     {
-      GemmParams p = gp_base(h->HN, D, y.fc1, M);
-      p.Ohi = h->F1.hi; p.Olo = h->F1.lo; p.ldo = 4 * D;
+      GemmParams p = gp_base(h->HN, am * D, y.fc1, M); p.a_il = il;
+      p.Ohi = h->F1.hi; p.Olo = h->F1.lo; p.ldo = am * 4 * D; p.o_il = il;
       KCHECK(h, gemm(h, p, EPI_GELU, A_ROWMAJOR, s, OVM_PROF_FC1));
     }
     {
-      GemmParams p = gp_base(h->F1, 4 * D, y.fc2, M);
+      GemmParams p = gp_base(h->F1, am * 4 * D, y.fc2, M); p.a_il = il;
       p.gamma = y.ls2; p.X = h->X; p.ldx = D;
       KCHECK(h, gemm(h, p, EPI_RESID, A_ROWMAJOR, s, OVM_PROF_FC2));
     }

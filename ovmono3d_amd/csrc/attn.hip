@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
   if (q_ok) {
-    const size_t orow = ((size_t)b * T + q) * p.ldo + head * 64;
+    const size_t orow = ((size_t)b * T + q) * p.ldo + (p.o_il ? head * 128 : head * 64);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -265,8 +265,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
           half_t hh, ll; split_f16(o0[t][4 * g + e] * inv, hh, ll); hv[e] = hh; lv[e] = ll;
         }
         const int d = 32 * t + 8 * g + 4 * h;
-        *(half4*)(p.Ohi + orow + d) = hv;
-        if (p.Olo) *(half4*)(p.Olo + orow + d) = lv;
+        const int oc = p.o_il ? il_col(d) : d;
+        *(half4*)(p.Ohi + orow + oc) = hv;
+        if (p.Olo) *(half4*)(p.Olo + orow + oc) = lv;
       }
   }
 }
@@ -358,7 +359,7 @@ __device__ __forceinline__ void attn_tail_body(const AttnParams& p, int tb, char
     o = wave_sum(o);
     if (lane == 0) {
       half_t hh, ll; split_f16(o * inv, hh, ll);
-      const size_t oo = ((size_t)b * T + q) * p.ldo + head * 64 + d;
+      const size_t oo = ((size_t)b * T + q) * p.ldo + (p.o_il ? il_col(head * 64 + d) : head * 64 + d);
       p.Ohi[oo] = hh;
       if (p.Olo) p.Olo[oo] = ll;
     }

@@ -60,6 +60,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Column of logical element k inside a row of an interleaved split image [k/32][hi 32 | lo 32] (the lo array starts 32 halves
+// after the hi array, so the same offset addresses both parts); row stride = 2 K.
+__host__ __device__ __forceinline__ int il_col(int k) { return ((k >> 5) << 6) | (k & 31); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

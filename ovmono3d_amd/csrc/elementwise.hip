@@ -123,8 +123,9 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
         half_t hh, ll; split_f16(y[r], hh, ll); h[r] = hh; l[r] = ll;
       }
       if (o.f32) ((f32x4*)(o.f32 + (size_t)row * o.ldf))[j] = y;
-      if (o.hi) ((half4*)(o.hi + orow * o.ld))[j] = h;
-      if (o.lo) ((half4*)(o.lo + orow * o.ld))[j] = l;
+      const int oc = o.il ? il_col(j * 4) : j * 4;
+      if (o.hi) *(half4*)(o.hi + orow * o.ld + oc) = h;
+      if (o.lo) *(half4*)(o.lo + orow * o.ld + oc) = l;
     }
   }
 }

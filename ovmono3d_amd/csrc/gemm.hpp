@@ -47,6 +47,7 @@ struct GemmParams {
                                                   // reverse window partition / un-shift / crop of a Swin block
   float* C; int ldc;                              // EPI_STORE: fp32 out (or null)
   half_t* Ohi; half_t* Olo; int ldo;              // EPI_STORE / EPI_GELU / EPI_CONVT: fp16 split out (or null)
+  int o_il;                                       // EPI_GELU: Ohi / Olo form an interleaved image (Olo = Ohi + 32, ldo = 2 N)
   int relu;                                       // EPI_STORE activation: 0 none, 1 ReLU, 2 GELU(erf)
   const float* R; int ldr;                        // EPI_STORE: optional fp32 residual added after the activation
   // EPI_STORE with padded-NHWC destination for Ohi/Olo (conv input): if padH>0, row m=(b,y,x) goes to
@@ -146,7 +147,7 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32
     half4 h, l;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { half_t hh, ll; split_f16(gelu_erf(v[r] + b4[r]), hh, ll); h[r] = hh; l[r] = ll; }
-    const size_t o = (size_t)m * p.ldo + n;
+    const size_t o = (size_t)m * p.ldo + (p.o_il ? il_col(n) : n);
     *(half4*)(p.Ohi + o) = h;
     if (p.Olo) *(half4*)(p.Olo + o) = l;
   } else if (EPI == EPI_QKV) {
@@ -674,6 +675,9 @@ __device__ __forceinline__ void gemm_tail_body(const GemmParams& p, int tb) {
 
 // Host launcher (defined in gemm.hip). npass in {1,3}.
 int launch_gemm(const GemmParams& p, int npass, int epi, int amode, hipStream_t stream);
+// gemm256.hip: 256 x 256 tiles, two wave groups ping-ponging LOAD / COMPUTE; needs interleaved A and W images, N % 256 == 0
+bool gemm256_supported(const GemmParams& p, int npass);
+int launch_gemm256(const GemmParams& p, int epi, int ksplit_hint, hipStream_t stream);
 // Tile-height override for tuning (0 = heuristic): 128 or 256.
 void gemm_set_force_bm(int bm);
 void gemm_set_tail_rows(int on);

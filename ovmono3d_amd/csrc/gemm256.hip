@@ -1,0 +1,273 @@
+// 256 x 256-tile split-precision GEMM for the large ViT contractions (qkv, fc1; fc2 / proj through split-K):
+//   C[m][n] = sum_k A[m][k] W[n][k],  A and W as interleaved split-fp16 images [row][k/32][hi 32 | lo 32] (128-byte k-groups).
+//
+// Why another kernel. With 128 x 128 tiles every k-group of 32 moves 32 KiB into LDS for 768 MFMA cycles per SIMD: the LDS-DMA
+// side (~45 GB/s per CU in-kernel) needs ~0.75 us for what the matrix cores do in ~0.35 us. A 256 x 256 tile moves
+// 64 KiB for 3072 MFMA cycles per SIMD - half the bytes per MFMA - which balances the two sides.
+//
+// Structure (after the 8-phase / two-wave-group scheme of cdna_hip_programming.md 5 and MI355X_MICROARCH.md "Two waves per
+// SIMD"): 8 waves = 2 (M) x 4 (N), each wave owns 128 x 64 outputs (128 accumulator registers) and walks them as four
+// 64 x 32 quadrants per k-group. A k-group is four 16-KiB half-tiles in LDS (A rows 0-127 / 128-255, W rows 0-127 / 128-255),
+// two k-groups resident (128 KiB). Every wave alternates a LOAD segment (fragment ds_reads + 2 LDS-DMA pieces = 1/8 of one
+// half-tile) and a COMPUTE segment (24 MFMAs = one quadrant x three passes), separated by raw s_barriers. The M = 1 wave group
+// runs one barrier behind the M = 0 group, and waves w and w + 4 share a SIMD, so on every SIMD one wave computes while the
+// other loads. Half-tiles are re-staged as soon as their last reader is done (W: after LOAD 1, A: after LOAD 3), two to six
+// segments ahead of their first use; one counted vmcnt per k-group keeps the younger pieces in flight across the barriers.
+//
+// Segment schedule of k-group t (G0 = waves 0-3, G1 = waves 4-7, one interval later):
+//   L1: read A(rows 0-63 of the wave's half) + all W fragments of t | stage A0(t+1)      C1: quadrant (0,0)
+//   L2:                                                             | stage A1(t+1)      C2: quadrant (0,1)
+//   L3: read A(rows 64-127)                                          | stage W0(t+2)      C3: quadrant (1,1)
+//   L4: (G1: counted wait)                                           | stage W1(t+2)      C4: quadrant (1,0)  (G0: counted wait)
+// Hazards. RAW: k-group t+1 is complete when its youngest pieces (A1(t+1), issued in L2 of t) have landed; both groups wait for
+// them before the barrier that precedes G0's L1 of t+1, leaving the two younger half-tiles W0/W1(t+2) in flight: vmcnt(4).
+// WAR: W(t) is last read in G1's L1 (interval 1) and re-staged from interval 4 on; A0(t) is last read in G0's L3 (interval 4)
+// and re-staged in L1 of t+1 (interval 8); A1(t) last read in G1's L3 (interval 5), re-staged in L2 of t+1 (interval 10); every
+// read is retired by the reader's lgkmcnt(0) at the start of the COMPUTE segment that follows it.
+#include <hip/hip_runtime.h>
+#include "gemm.hpp"
+
+namespace ovm {
+
+namespace {
+
+constexpr int kHalf = 128 * 128;              // one half-tile: 128 rows x 128 bytes
+// LDS map: region r in {A0, A1, W0, W1} of buffer b at (2 r + b) * kHalf - the two buffers of a region are 16 KiB apart, so
+// with the k-loop unrolled by two the buffer select folds into the 16-bit immediate offset of ds_read_b128
+constexpr int kRegion = 2 * kHalf;
+
+__device__ __forceinline__ int frag_off(int row, int chunk) { return row * 128 + (chunk ^ ((row >> 1) & 7)) * 16; }
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
+  if ((int)blockIdx.x >= p.main_tiles) { gemm_tail_body<3, EPI, A_ROWMAJOR, true>(p, (int)blockIdx.x - p.main_tiles); return; }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wc = wave & 3;
+  const int tiles_m = (p.M + 255) / 256;
+  const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+  const int tiles = p.main_tiles / ksplit;
+  const int tiles_n = tiles / tiles_m;
+  const int ks = (int)blockIdx.x / tiles;
+  // XCD-aware order: the workgroups that share an XCD (id % 8) take a compact patch of GROUP_M row tiles x all column tiles
+  int pid = xcd_remap((int)blockIdx.x - ks * tiles, tiles);
+  constexpr int GROUP_M = 4;
+  const int in_group = GROUP_M * tiles_n;
+  const int gid = pid / in_group;
+  const int first_m = gid * GROUP_M;
+  const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+  const int tm = first_m + (pid % in_group) % gsz;
+  const int tn = (pid % in_group) / gsz;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nk_all = p.K / 32;
+  const int kt0 = (ksplit > 1) ? ks * p.kchunk : 0;
+  const int nk = (ksplit > 1) ? ((nk_all - kt0 < p.kchunk) ? nk_all - kt0 : p.kchunk) : nk_all;
+
+  // ---- staging: wave w moves pieces w and w + 8 (8 rows x 128 B each) of every half-tile
+  uint32_t aoff[2][2], woff[2][2];            // [half][piece]
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = (wave + 8 * q) * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      int m = m0 + hf * 128 + row; if (m > p.M - 1) m = p.M - 1;
+      aoff[hf][q] = (uint32_t)m * (uint32_t)p.lda + chunk * 8;
+      woff[hf][q] = (uint32_t)(n0 + hf * 128 + row) * (uint32_t)p.ldw + chunk * 8;
+    }
+  auto stage_a = [&](int t, int hf) {
+    char* base = smem + hf * kRegion + (t & 1) * kHalf + wave * 1024;
+    const uint32_t ko = (uint32_t)(kt0 + t) * 64;
+    glds16(p.Ahi + aoff[hf][0] + ko, base);
+    glds16(p.Ahi + aoff[hf][1] + ko, base + 8 * 1024);
+  };
+  auto stage_w = [&](int t, int hf) {
+    char* base = smem + (2 + hf) * kRegion + (t & 1) * kHalf + wave * 1024;
+    const uint32_t ko = (uint32_t)(kt0 + t) * 64;
+    glds16(p.Whi + woff[hf][0] + ko, base);
+    glds16(p.Whi + woff[hf][1] + ko, base + 8 * 1024);
+  };
+
+  // ---- fragment addresses (16x16x32 operands: lane (fr, fq) holds k = 8 fq .. 8 fq + 7 of row fr; hi chunk fq, lo chunk 4 + fq)
+  const int fr = lane & 15, fq = lane >> 4;
+  int oa_hi[2][4], oa_lo[2][4], ow_hi[4], ow_lo[4];
+#pragma unroll
+  for (int ra = 0; ra < 2; ++ra)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = ra * 64 + i * 16 + fr;
+      oa_hi[ra][i] = grp * kRegion + frag_off(row, fq);
+      oa_lo[ra][i] = grp * kRegion + frag_off(row, 4 + fq);
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wc & 1) * 64 + i * 16 + fr;
+    ow_hi[i] = (2 + (wc >> 1)) * kRegion + frag_off(row, fq);
+    ow_lo[i] = (2 + (wc >> 1)) * kRegion + frag_off(row, 4 + fq);
+  }
+
+  f32x4 acc[2][4][4];                         // [row half][mi][ni]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[a][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  half8 ah[4], al[4], wh[4], wl[4];
+
+#define OVM_READ_A(RA, BASE)                                                           \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
+    ah[i] = *(const half8*)((BASE) + oa_hi[RA][i]);                                    \
+    al[i] = *(const half8*)((BASE) + oa_lo[RA][i]);                                    \
+  }
+#define OVM_READ_W(BASE)                                                               \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
+    wh[i] = *(const half8*)((BASE) + ow_hi[i]);                                        \
+    wl[i] = *(const half8*)((BASE) + ow_lo[i]);                                        \
+  }
+#define OVM_QUAD(RA, CB)                                                               \
+  __builtin_amdgcn_s_setprio(1);                                                       \
+  _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                     \
+  _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                   \
+    f32x4 c_ = acc[RA][mi][(CB) * 2 + ni];                                             \
+    c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[(CB) * 2 + ni], ah[mi], c_, 0, 0, 0); \
+    c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[(CB) * 2 + ni], al[mi], c_, 0, 0, 0); \
+    c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[(CB) * 2 + ni], ah[mi], c_, 0, 0, 0); \
+    acc[RA][mi][(CB) * 2 + ni] = c_;                                                   \
+  }                                                                                    \
+  __builtin_amdgcn_s_setprio(0);
+#define OVM_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+  // ---- prologue: k-group 0 complete, W0 / W1 of k-group 1
+  stage_a(0, 0); stage_a(0, 1); stage_w(0, 0); stage_w(0, 1);
+  if (nk > 1) { stage_w(1, 0); stage_w(1, 1); wait_vmcnt<4>(); } else { wait_vmcnt<0>(); }
+  OVM_BAR();
+  if (grp == 1) OVM_BAR();                    // G1 runs one interval behind G0
+
+#define OVM_TILE(T_, B_)                                                               \
+  {                                                                                    \
+    const int t = (T_);                                                                \
+    const char* base = smem + (B_) * kHalf;                                            \
+    OVM_READ_A(0, base)                       /* L1 */                                 \
+    OVM_READ_W(base)                                                                   \
+    if (t + 1 < nk) stage_a(t + 1, 0);                                                 \
+    OVM_BAR();                                                                         \
+    OVM_QUAD(0, 0)                            /* C1 */                                 \
+    OVM_BAR();                                                                         \
+    if (t + 1 < nk) stage_a(t + 1, 1);        /* L2 */                                 \
+    OVM_BAR();                                                                         \
+    OVM_QUAD(0, 1)                            /* C2 */                                 \
+    OVM_BAR();                                                                         \
+    OVM_READ_A(1, base)                       /* L3 */                                 \
+    if (t + 2 < nk) stage_w(t + 2, 0);                                                 \
+    OVM_BAR();                                                                         \
+    OVM_QUAD(1, 1)                            /* C3 */                                 \
+    OVM_BAR();                                                                         \
+    if (t + 2 < nk) stage_w(t + 2, 1);        /* L4 */                                 \
+    if (grp == 1) { if (t + 2 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>(); }           \
+    OVM_BAR();                                                                         \
+    OVM_QUAD(1, 0)                            /* C4 */                                 \
+    if (grp == 0) { if (t + 2 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>(); }           \
+    OVM_BAR();                                                                         \
+  }
+  int t2 = 0;
+  for (; t2 + 1 < nk; t2 += 2) {
+    OVM_TILE(t2, 0)
+    OVM_TILE(t2 + 1, 1)
+  }
+  if (t2 < nk) OVM_TILE(t2, 0)
+#undef OVM_TILE
+  if (grp == 0) OVM_BAR();                    // same number of barriers for every wave
+#undef OVM_READ_A
+#undef OVM_READ_W
+#undef OVM_QUAD
+
+  // ---- epilogue: lane holds (m = .. + fr, n = .. + fq * 4 .. + 3)
+  const int mb = m0 + grp * 128, nb = n0 + wc * 64;
+#pragma unroll
+  for (int ra = 0; ra < 2; ++ra)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int m = mb + ra * 64 + mi * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int n = nb + ni * 16 + fq * 4;
+        if (ksplit > 1) { if (n < p.N) *(f32x4*)(p.part + ((size_t)ks * p.M + m) * p.N + n) = acc[ra][mi][ni]; }
+        else epilogue4<EPI>(p, m, n, acc[ra][mi][ni]);
+      }
+    }
+#undef OVM_BAR
+}
+
+float* g_ws256 = nullptr; size_t g_ws256_cap = 0;
+
+template <int EPI>
+int launch256(const GemmParams& p, int want_split, hipStream_t s) {
+  constexpr int smem = 8 * kHalf;
+  GemmParams q = p;
+  q.M_total = p.M; q.tail_begin = p.M; q.ldw = 2 * p.K;
+  q.ksplit = 1; q.kchunk = 0; q.part = nullptr;
+  int tail_blocks = 0;
+  const int tail = p.M % 256;
+  if (tail > 0 && tail <= 8 && p.M > 256) {             // leftover rows (the cls token): dot-product workgroups of the same launch
+    q.tail_begin = p.M - tail; q.M = q.tail_begin;
+    tail_blocks = tail * ((p.N + 4 * 8 - 1) / (4 * 8));
+  }
+  const int tiles_m = (q.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+  const int nk = p.K / 32;
+  int ks = want_split;
+  if (ks > 1 && tail_blocks == 0 && p.N % 4 == 0) {
+    if (ks > nk / 8) ks = nk / 8;
+    if (ks > 1) {
+      const int chunk = (nk + ks - 1) / ks;
+      ks = (nk + chunk - 1) / chunk;
+      const size_t need = (size_t)ks * p.M * p.N * sizeof(float);
+      float* ws = p.part_ws; size_t cap = p.part_cap;
+      if (!ws) {
+        if (g_ws256_cap < need) {
+          if (g_ws256) { (void)hipDeviceSynchronize(); (void)hipFree(g_ws256); }
+          g_ws256_cap = need;
+          if (hipMalloc((void**)&g_ws256, need) != hipSuccess) { g_ws256 = nullptr; g_ws256_cap = 0; return OVM_ERR_HIP; }
+        }
+        ws = g_ws256; cap = g_ws256_cap;
+      }
+      if (cap < need) return OVM_ERR_CAPACITY;
+      q.ksplit = ks; q.kchunk = chunk; q.part = ws;
+    }
+  }
+  q.main_tiles = tiles_m * tiles_n * q.ksplit;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return OVM_ERR_HIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(q.main_tiles + tail_blocks), dim3(512), smem, s, q);
+  if (q.ksplit > 1) {
+    const long n = (long)p.M * (p.N / 4);
+    hipLaunchKernelGGL((splitk_epilogue_kernel<EPI>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, q);
+  }
+  return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
+
+}  // namespace
+
+bool gemm256_supported(const GemmParams& p, int npass) {
+  return npass == 3 && p.a_il && p.Alo == p.Ahi + 32 && p.Wlo == p.Whi + 32 && p.K % 32 == 0 && p.lda == 2 * p.K && p.N % 256 == 0;
+}
+
+// ksplit_hint <= 1: no split-K
+int launch_gemm256(const GemmParams& p, int epi, int ksplit_hint, hipStream_t s) {
+  if (!gemm256_supported(p, 3)) return OVM_ERR_INVALID;
+  if (p.M <= 0 || p.N <= 0) return OVM_OK;
+  switch (epi) {
+    case EPI_STORE: return launch256<EPI_STORE>(p, ksplit_hint, s);
+    case EPI_RESID: return launch256<EPI_RESID>(p, ksplit_hint, s);
+    case EPI_GELU:  return launch256<EPI_GELU>(p, ksplit_hint, s);
+    case EPI_QKV:   return launch256<EPI_QKV>(p, ksplit_hint, s);
+  }
+  return OVM_ERR_INVALID;
+}
+
+}  // namespace ovm

@@ -15,11 +15,13 @@ struct LnOut {
   half_t* hi; half_t* lo; int ld;   // fp16 split output (row stride ld), or null
   float* f32; int ldf;              // fp32 output, or null
   int padH, padW;                   // >0: hi/lo rows go to the interior of a zero-bordered NHWC image
+  int il;                           // hi/lo form an interleaved image [row][k/32][hi 32 | lo 32] (lo = hi + 32, ld = 2 D)
 };
 
 struct AttnParams {
   const half_t *Qhi, *Qlo, *Khi, *Klo, *Vhi, *Vlo;   // Q,K [B][h][T][64]; V^T [B][h][64][Tpad] (permuted tokens)
   half_t *Ohi, *Olo; int ldo;                        // out rows b*T + t, column head*64 + d
+  int o_il;                                          // output is an interleaved split image (Olo = Ohi + 32, ldo = 2 D)
   int B, heads, T, Tpad;
   int corun;                                         // another stream's short kernels run beside this launch: keep to one workgroup per CU
   int Tq, main_blocks;                               // set by the launcher: queries / workgroups of the tiled part

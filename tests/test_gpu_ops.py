@@ -286,3 +286,47 @@ def test_gdino_glue_matches_oracle(device):
     assert torch.equal(c.cpu(), rc)
     assert_close(b, rb, 1e-5, "gdino boxes")
     assert_close(s, rs, 1e-5, "gdino scores")
+
+
+@pytest.mark.parametrize("M,N,K,ksplit", [(256, 256, 64, 1), (300, 512, 96, 1), (4097, 768, 256, 1), (1024, 256, 1024, 4), (700, 512, 2048, 8),
+                                          (512, 256, 32, 1)])
+def test_gemm256_two_wave_group_kernel(device, M, N, K, ksplit):
+    """The 256 x 256 kernel (gemm256.hip: two wave groups ping-ponging LOAD / COMPUTE segments, re-staged half-tiles, counted
+    vmcnt across raw barriers) through ovm_op_gemm: exact on small integers with an asymmetric W (fragment / quadrant maps),
+    fp32-class on random data, ragged M (clamped rows, the dot-product tail workgroups at M % 256 <= 8), odd and even numbers
+    of k-groups, split-K. Repeated launches must agree bit for bit (the hazards are placed by count, not by luck)."""
+    import ctypes as C
+    L = _lib()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    try:
+        assert L.ovm_tune_set(b"op_gemm256", ksplit) == 0
+        # exact integers
+        A = torch.zeros(M, K)
+        A[torch.arange(M), torch.arange(M) % K] = 1.0
+        A[:, 5 % K] += 2.0
+        A[:, (K - 1)] -= 3.0
+        W = (torch.arange(N * K).reshape(N, K) % 13 - 6).float()
+        A, W = A.to(device), W.to(device)
+        ah, al = _split(A); wh, wl = _split(W)
+        a_hi, a_lo, lda, w_hi, w_lo, keep = _gemm_args(ah, al, wh, wl, K, 3, True)
+        Cout = torch.full((M, N), 7.0, device=device)
+        assert L.ovm_op_gemm(a_hi, a_lo, lda, w_hi, w_lo, M, N, K, None, 0, Cout.data_ptr(), N, 3, _stream()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(Cout, A @ W.T)
+        # random data
+        A = torch.randn(M, K, generator=g).to(device)
+        W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(device)
+        bias = torch.randn(N, generator=g).to(device)
+        ah, al = _split(A); wh, wl = _split(W)
+        a_hi, a_lo, lda, w_hi, w_lo, keep = _gemm_args(ah, al, wh, wl, K, 3, True)
+        outs = []
+        for rep in range(3):
+            Cout = torch.full((M, N), 7.0, device=device)
+            assert L.ovm_op_gemm(a_hi, a_lo, lda, w_hi, w_lo, M, N, K, bias.data_ptr(), 1, Cout.data_ptr(), N, 3, _stream()) == 0
+            torch.cuda.synchronize()
+            outs.append(Cout)
+        ref = torch.relu(A.double() @ W.double().T + bias.double()).float()
+        assert_close(outs[0], ref, max(2e-6, 3e-8 * math.sqrt(K)), f"gemm256 {M}x{N}x{K} split {ksplit}")
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    finally:
+        L.ovm_tune_set(b"op_gemm256", 0)
