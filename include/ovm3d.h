@@ -281,6 +281,8 @@ int ovm_g_topk(const float* scores, int32_t n, int32_t k, int32_t* out_idx, ovm_
  *   gemm256 0|1 (256 x 256 two-wave-group kernel for qkv / fc1), op_gemm256 n (ovm_op_gemm on that kernel, n = split-K hint),
  *   attn_tail 0|1, glin_small_max_tiles (-1 = heuristic), glin_target_blocks, glin_max_ksplit, glin_stages 1|2, gbmm_tiled 0|1 */
 int ovm_tune_set(const char* key, int32_t value);
+/* diagnostic builds: device pointer for a named debug hook ("gemm256_stamps": u64 [8 waves][128] s_memtime stamps of workgroup 0) */
+int ovm_debug_set_ptr(const char* key, void* ptr);
 
 /* --- introspection for tests: copy a named intermediate of the last forward into dst (device).
  * names: "tokens" [B*T][D] fp32, "p2" / "p3" / "p4". Returns the element count or a negative error. */

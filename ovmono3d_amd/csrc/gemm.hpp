@@ -32,6 +32,7 @@ struct GemmParams {
   // split-K (wave-specialised kernel, set by the launcher for thin grids with a long K): workgroup = (tile, k-slice); slices
   // write raw fp32 partial tiles to `part` [ksplit][M][N] and splitk_epilogue_kernel sums them and applies the epilogue
   int ksplit, kchunk; float* part;
+  unsigned long long* stamps;                     // diagnostic builds only (gemm256 stamp variant): s_memtime per barrier, [wave][128]
   float* part_ws; size_t part_cap;                // caller-owned split-K workspace (bytes); null: the launcher's process-global one
                                                   // (which may be re-allocated - not usable under HIP-graph capture / replay)
   int ws_slot;                                    // which split-K workspace the launcher may use: callers that run concurrently on

@@ -7,23 +7,16 @@
 //
 // Structure (after the 8-phase / two-wave-group scheme of cdna_hip_programming.md 5 and MI355X_MICROARCH.md "Two waves per
 // SIMD"): 8 waves = 2 (M) x 4 (N), each wave owns 128 x 64 outputs (128 accumulator registers) and walks them as four
-// 64 x 32 quadrants per k-group. A k-group is four 16-KiB half-tiles in LDS (A rows 0-127 / 128-255, W rows 0-127 / 128-255),
-// two k-groups resident (128 KiB). Every wave alternates a LOAD segment (fragment ds_reads + 2 LDS-DMA pieces = 1/8 of one
-// half-tile) and a COMPUTE segment (24 MFMAs = one quadrant x three passes), separated by raw s_barriers. The M = 1 wave group
+// 64 x 32 quadrants per k-group, two quadrants per COMPUTE segment. A k-group is four 16-KiB half-tiles in LDS (A rows 0-127 / 128-255, W rows 0-127 / 128-255),
+// two k-groups resident (128 KiB). Every wave alternates a LOAD segment (fragment ds_reads + 4 LDS-DMA pieces = 1/8 of two
+// half-tiles) and a COMPUTE segment (48 MFMAs = two quadrants x three passes), separated by raw s_barriers. The M = 1 wave group
 // runs one barrier behind the M = 0 group, and waves w and w + 4 share a SIMD, so on every SIMD one wave computes while the
 // other loads. Half-tiles are re-staged as soon as their last reader is done (W: after LOAD 1, A: after LOAD 3), two to six
 // segments ahead of their first use; one counted vmcnt per k-group keeps the younger pieces in flight across the barriers.
 //
-// Segment schedule of k-group t (G0 = waves 0-3, G1 = waves 4-7, one interval later):
-//   L1: read A(rows 0-63 of the wave's half) + all W fragments of t | stage A0(t+1)      C1: quadrant (0,0)
-//   L2:                                                             | stage A1(t+1)      C2: quadrant (0,1)
-//   L3: read A(rows 64-127)                                          | stage W0(t+2)      C3: quadrant (1,1)
-//   L4: (G1: counted wait)                                           | stage W1(t+2)      C4: quadrant (1,0)  (G0: counted wait)
-// Hazards. RAW: k-group t+1 is complete when its youngest pieces (A1(t+1), issued in L2 of t) have landed; both groups wait for
-// them before the barrier that precedes G0's L1 of t+1, leaving the two younger half-tiles W0/W1(t+2) in flight: vmcnt(4).
-// WAR: W(t) is last read in G1's L1 (interval 1) and re-staged from interval 4 on; A0(t) is last read in G0's L3 (interval 4)
-// and re-staged in L1 of t+1 (interval 8); A1(t) last read in G1's L3 (interval 5), re-staged in L2 of t+1 (interval 10); every
-// read is retired by the reader's lgkmcnt(0) at the start of the COMPUTE segment that follows it.
+// Segment schedule of k-group t (G0 = waves 0-3, G1 = waves 4-7, one interval later): see OVM_TILE below. RAW: k-group t+1 is
+// complete when its youngest pieces (A0/A1(t+1), issued in La of t) have landed; both groups wait for them before the barrier that
+// precedes G0's La of t+1, leaving the two younger half-tiles W0/W1(t+2) in flight: vmcnt(4).
 #include <hip/hip_runtime.h>
 #include "gemm.hpp"
 
@@ -38,10 +31,14 @@ constexpr int kRegion = 2 * kHalf;
 
 __device__ __forceinline__ int frag_off(int row, int chunk) { return row * 128 + (chunk ^ ((row >> 1) & 7)) * 16; }
 
-template <int EPI>
+// STAMP = 1 is a diagnostic build (never used by the engine): every wave of workgroup 0 records s_memtime after each barrier of
+// the first k-groups into the unused top 32 KiB of the LDS and dumps them to p.stamps at the end (cdna_hip_programming.md 7,
+// "In-kernel stamps": read the SHARES of the segments, not the run time of this build).
+template <int EPI, int STAMP = 0>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   if ((int)blockIdx.x >= p.main_tiles) { gemm_tail_body<3, EPI, A_ROWMAJOR, true>(p, (int)blockIdx.x - p.main_tiles); return; }
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned long long t_entry = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wc = wave & 3;
@@ -137,7 +134,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     acc[RA][mi][(CB) * 2 + ni] = c_;                                                   \
   }                                                                                    \
   __builtin_amdgcn_s_setprio(0);
-#define OVM_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+  int stamp_i = 0;
+  unsigned long long* stamp_lds = (unsigned long long*)(smem + 8 * 64 * 68 * 4) + wave * 128;
+#define OVM_STAMP() do { if (STAMP && blockIdx.x == 0 && stamp_i < 124) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    if (lane == 0) stamp_lds[stamp_i] = t_; ++stamp_i; } } while (0)
+#define OVM_BAR() do { __builtin_amdgcn_sched_barrier(0); OVM_STAMP(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); OVM_STAMP(); } while (0)
 
   // ---- prologue: k-group 0 complete, W0 / W1 of k-group 1
   stage_a(0, 0); stage_a(0, 1); stage_w(0, 0); stage_w(0, 1);
@@ -145,29 +146,31 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   OVM_BAR();
   if (grp == 1) OVM_BAR();                    // G1 runs one interval behind G0
 
+// Four segments per k-group (two quadrants = 48 MFMAs per COMPUTE segment): half as many barriers per MFMA as one quadrant per
+// segment (stamps: a barrier costs ~140 dead cycles to the last arriver; 24-MFMA segments ran at 56 % of the MFMA issue rate).
+//   La: read A(rows 0-63) + all W of t | stage A0(t+1), A1(t+1)         Ca: quadrants (0,0) (0,1)
+//   Lb: read A(rows 64-127)            | stage W0(t+2), W1(t+2), wait   Cb: quadrants (1,1) (1,0)   (G0 waits at the end of Cb)
+// LOAD segments end with lgkmcnt(0) (they idle at the barrier anyway), so a region is free once the barrier after its last read
+// has passed: W(t) after interval 1 (staged in 2, 3), A0(t) after 2, A1(t) after 3 (staged in intervals 4, 5 = La of t+1).
 #define OVM_TILE(T_, B_)                                                               \
   {                                                                                    \
     const int t = (T_);                                                                \
     const char* base = smem + (B_) * kHalf;                                            \
-    OVM_READ_A(0, base)                       /* L1 */                                 \
+    OVM_READ_A(0, base)                       /* La */                                 \
     OVM_READ_W(base)                                                                   \
-    if (t + 1 < nk) stage_a(t + 1, 0);                                                 \
+    if (t + 1 < nk) { stage_a(t + 1, 0); stage_a(t + 1, 1); }                          \
+    __builtin_amdgcn_s_waitcnt(0xC07F);       /* lgkmcnt(0) */                         \
     OVM_BAR();                                                                         \
-    OVM_QUAD(0, 0)                            /* C1 */                                 \
+    OVM_QUAD(0, 0)                            /* Ca */                                 \
+    OVM_QUAD(0, 1)                                                                     \
     OVM_BAR();                                                                         \
-    if (t + 1 < nk) stage_a(t + 1, 1);        /* L2 */                                 \
-    OVM_BAR();                                                                         \
-    OVM_QUAD(0, 1)                            /* C2 */                                 \
-    OVM_BAR();                                                                         \
-    OVM_READ_A(1, base)                       /* L3 */                                 \
-    if (t + 2 < nk) stage_w(t + 2, 0);                                                 \
-    OVM_BAR();                                                                         \
-    OVM_QUAD(1, 1)                            /* C3 */                                 \
-    OVM_BAR();                                                                         \
-    if (t + 2 < nk) stage_w(t + 2, 1);        /* L4 */                                 \
+    OVM_READ_A(1, base)                       /* Lb */                                 \
+    if (t + 2 < nk) { stage_w(t + 2, 0); stage_w(t + 2, 1); }                          \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                \
     if (grp == 1) { if (t + 2 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>(); }           \
     OVM_BAR();                                                                         \
-    OVM_QUAD(1, 0)                            /* C4 */                                 \
+    OVM_QUAD(1, 1)                            /* Cb */                                 \
+    OVM_QUAD(1, 0)                                                                     \
     if (grp == 0) { if (t + 2 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>(); }           \
     OVM_BAR();                                                                         \
   }
@@ -183,29 +186,86 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #undef OVM_READ_W
 #undef OVM_QUAD
 
-  // ---- epilogue: lane holds (m = .. + fr, n = .. + fq * 4 .. + 3)
+  const unsigned long long t_loop_end = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;
+  // ---- epilogue through LDS. The MFMA layout gives a lane 4 columns of 16 different rows: stored directly, every store
+  // instruction touches 16 rows x 64 B, and with all 256 workgroups of a one-round grid reaching the epilogue together that
+  // cost 30 % of the kernel (stamps: 57k of 192k cycles at the fc1 shape). Each wave stages 64 x 64 accumulators in the drained
+  // ring and re-reads them row-major, so that 16 lanes cover one row: 256 contiguous bytes of fp32 / of the interleaved split
+  // image [hi 32 | lo 32 | hi 32 | lo 32] per row and instruction.
+  constexpr int TLD = 68;                                      // padded row stride (floats)
+  float* tile = (float*)smem + wave * (64 * TLD);
   const int mb = m0 + grp * 128, nb = n0 + wc * 64;
+  bool vt_tile = false;
+  if (EPI == EPI_QKV && ksplit == 1) vt_tile = (nb / (p.N / 3)) == 2;   // wave-uniform: head blocks are 64 wide
 #pragma unroll
-  for (int ra = 0; ra < 2; ++ra)
+  for (int ra = 0; ra < 2; ++ra) {
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int m = mb + ra * 64 + mi * 16 + fr;
-      if (m >= p.M) continue;
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int n = nb + ni * 16 + fq * 4;
-        if (ksplit > 1) { if (n < p.N) *(f32x4*)(p.part + ((size_t)ks * p.M + m) * p.N + n) = acc[ra][mi][ni]; }
-        else epilogue4<EPI>(p, m, n, acc[ra][mi][ni]);
+      for (int ni = 0; ni < 4; ++ni) *(f32x4*)(tile + (mi * 16 + fr) * TLD + ni * 16 + fq * 4) = acc[ra][mi][ni];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int mrow0 = mb + ra * 64;
+    if (!vt_tile) {
+      const int col = (lane & 15) * 4;
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const f32x4 v = *(const f32x4*)(tile + row * TLD + col);
+        const int m = mrow0 + row, n = nb + col;
+        if (m < p.M) {
+          if (ksplit > 1) { if (n < p.N) *(f32x4*)(p.part + ((size_t)ks * p.M + m) * p.N + n) = v; }
+          else epilogue4<EPI>(p, m, n, v);
+        }
+      }
+    } else {
+      // V^T [b][head][d][Tpad]: tokens are the contiguous axis, so lanes run along m (one 2-byte element each, 128 B per store)
+      const int m = mrow0 + lane;
+      if (m < p.M) {
+        const int Dm = p.N / 3;
+        const int head = (nb - 2 * Dm) >> 6;
+        const int b = m / p.T, t = m - b * p.T;
+        const int tp = (t & ~15) | (t & 3) | ((t & 4) << 1) | ((t & 8) >> 1);
+        const size_t o0 = ((size_t)(b * p.heads + head) * 64) * p.Tpad + tp;
+        for (int d = 0; d < 64; ++d) {
+          float x = tile[lane * TLD + d];
+          if (p.bias) x += p.bias[nb + d];
+          half_t hh, ll; split_f16(x, hh, ll);
+          p.Vhi[o0 + (size_t)d * p.Tpad] = hh;
+          if (p.Vlo) p.Vlo[o0 + (size_t)d * p.Tpad] = ll;
+        }
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
 #undef OVM_BAR
+  if (STAMP && blockIdx.x == 0 && p.stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t_exit = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    if (lane == 0) {
+      for (int i = 0; i < 124; ++i) p.stamps[wave * 128 + i] = (i < stamp_i) ? stamp_lds[i] : 0ull;
+      p.stamps[wave * 128 + 124] = (unsigned long long)stamp_i;
+      p.stamps[wave * 128 + 125] = t_entry; p.stamps[wave * 128 + 126] = t_loop_end; p.stamps[wave * 128 + 127] = t_exit;
+    }
+  }
 }
 
 float* g_ws256 = nullptr; size_t g_ws256_cap = 0;
 
 template <int EPI>
 int launch256(const GemmParams& p, int want_split, hipStream_t s) {
-  constexpr int smem = 8 * kHalf;
+  constexpr int smem = 8 * 64 * 68 * 4;                    // = 139,264 B: the epilogue's eight padded 64 x 64 staging tiles (the ring needs 131,072)
+  static_assert(smem >= 8 * kHalf, "ring");
+  if (EPI == EPI_STORE && p.stamps) {                     // diagnostic build
+    GemmParams q = p;
+    q.M_total = p.M; q.tail_begin = p.M; q.ldw = 2 * p.K; q.ksplit = 1; q.kchunk = 0; q.part = nullptr;
+    q.main_tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI_STORE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem + 8192);
+    hipLaunchKernelGGL((gemm256_kernel<EPI_STORE, 1>), dim3(q.main_tiles), dim3(512), smem + 8192, s, q);
+    return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+  }
   GemmParams q = p;
   q.M_total = p.M; q.tail_begin = p.M; q.ldw = 2 * p.K;
   q.ksplit = 1; q.kchunk = 0; q.part = nullptr;

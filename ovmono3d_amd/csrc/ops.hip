@@ -56,6 +56,8 @@ struct Tmp {
 };
 }  // namespace
 
+namespace ovm { void set_use_gemm256(int v); }
+
 extern "C" {
 
 int ovm_op_split_f16(const float* x, int64_t n, uint16_t* hi, uint16_t* lo, ovm_stream_t stream) {
@@ -66,7 +68,7 @@ int ovm_op_split_f16(const float* x, int64_t n, uint16_t* hi, uint16_t* lo, ovm_
 
 // C[M][N] = A[M][K] W[N][K]^T (+bias)(+relu). W must be padded to a multiple of 128 rows by the caller.
 static int g_op_gemm256 = 0;
-namespace ovm { void set_use_gemm256(int v); }
+static unsigned long long* g_gemm256_stamps = nullptr;   // diagnostic: device buffer [8][128] set through ovm_debug_set_ptr
 
 int ovm_op_gemm(const uint16_t* a_hi, const uint16_t* a_lo, int32_t lda, const uint16_t* w_hi, const uint16_t* w_lo,
                 int32_t M, int32_t N, int32_t K, const float* bias, int32_t relu, float* c, int32_t ldc,
@@ -81,6 +83,7 @@ int ovm_op_gemm(const uint16_t* a_hi, const uint16_t* a_lo, int32_t lda, const u
   p.M = M; p.N = N; p.K = K; p.bias = bias; p.relu = relu; p.C = c; p.ldc = ldc;
   if (g_op_gemm256 > 0) {                                     // tests / micro-benchmarks: force the 256 x 256 kernel (value = split-K hint)
     if (!gemm256_supported(p, precision)) return OVM_ERR_INVALID;
+    p.stamps = g_gemm256_stamps;
     return launch_gemm256(p, EPI_STORE, g_op_gemm256, (hipStream_t)stream);
   }
   return launch_gemm(p, precision, EPI_STORE, A_ROWMAJOR, (hipStream_t)stream);
@@ -199,6 +202,12 @@ int ovm_tune_set(const char* key, int32_t value) {
   if (!strcmp(key, "glin_max_ksplit")) { gemm_small_set(-1, value); return OVM_OK; }
   if (!strcmp(key, "gemm256")) { ovm::set_use_gemm256(value); return OVM_OK; }          // engine: 256 x 256 kernel for qkv / fc1 (default 1)
   if (!strcmp(key, "op_gemm256")) { g_op_gemm256 = value; return OVM_OK; }              // ovm_op_gemm: force it, value = split-K hint
+  return OVM_ERR_INVALID;
+}
+
+/* diagnostics: hands a device pointer to a named debug hook ("gemm256_stamps": u64 [8][128], NULL switches it off) */
+int ovm_debug_set_ptr(const char* key, void* ptr) {
+  if (key && !strcmp(key, "gemm256_stamps")) { g_gemm256_stamps = (unsigned long long*)ptr; return OVM_OK; }
   return OVM_ERR_INVALID;
 }
 

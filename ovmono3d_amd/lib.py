@@ -64,7 +64,7 @@ EXPORTS = [
     "ovm_g_pack_weight", "ovm_g_linear", "ovm_g_layernorm", "ovm_g_bmm", "ovm_g_bmm2", "ovm_g_softmax", "ovm_g_softmax2", "ovm_g_eltwise", "ovm_g_gather_rows",
     "ovm_g_groupnorm", "ovm_g_msdeform", "ovm_g_sine_embed", "ovm_g_normalize_image", "ovm_g_topk", "ovm_g_rowmax",
     "ovm_gdino_create", "ovm_gdino_destroy", "ovm_gdino_last_error", "ovm_gdino_forward", "ovm_gdino_detect", "ovm_gdino_set_force_topk",
-    "ovm_gdino_debug_copy",
+    "ovm_gdino_debug_copy", "ovm_debug_set_ptr",
 ]
 PROF_NAMES = ("attn", "qkv", "proj", "fc1", "fc2", "ln")
 
@@ -111,6 +111,7 @@ def load() -> C.CDLL:
     lib.ovm_comm_init.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     lib.ovm_comm_destroy.argtypes = [vp]
     lib.ovm_tune_set.argtypes = [C.c_char_p, i32]
+    lib.ovm_debug_set_ptr.argtypes = [C.c_char_p, vp]
     lib.ovm_host_pil_bilinear_coeffs.argtypes = [i32, i32, vp, vp, i32]
     lib.ovm_resize_bilinear_u8.argtypes = [vp, i32, i32, i32, i64, i64, i64, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.ovm_box3d_iou.argtypes = [vp, vp, i32, i32, f32, f32, vp, vp, vp]
