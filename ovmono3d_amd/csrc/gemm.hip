@@ -57,8 +57,10 @@ static int launch_ws(const GemmParams& p, hipStream_t s) {
   const int nk = p.K / BK;
   // a thin grid with a long reduction (the RoI heads' fc1: <= 64 tiles, 392 k-tiles) leaves most CUs idle for hundreds of
   // k-steps: split K over workgroups (deterministic: partial tiles + one reduce/epilogue pass)
-  if (g_splitk && (EPI == EPI_STORE) && tiles_full <= 64 && nk >= 64 && p.N % 4 == 0) {
-    int ks = 256 / tiles_full; if (ks > 16) ks = 16; if (ks > nk / 16) ks = nk / 16;
+  // (also the GroundingDINO engine's Swin proj / fc2 GEMMs: 40-90 tiles with 16-64 k-tiles, residual epilogue: the reduce
+  // pass applies any epilogue, EPI_QKV's V^T scatter excepted)
+  if (g_splitk && (EPI != EPI_QKV && EPI != EPI_PATCH && EPI != EPI_CONVT) && tiles_full <= 96 && nk >= 32 && p.N % 4 == 0) {
+    int ks = 256 / tiles_full; if (ks > 16) ks = 16; if (ks > nk / 8) ks = nk / 8;
     if (ks > 1) {
       const int chunk = (nk + ks - 1) / ks;
       ks = (nk + chunk - 1) / chunk;
