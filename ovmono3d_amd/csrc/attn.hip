@@ -19,6 +19,10 @@ namespace ovm {
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
+template <int N> __device__ __forceinline__ void wait_vmcnt_n() {
+  __builtin_amdgcn_s_waitcnt((N & 0xF) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
 constexpr float kPShift = 14.0f;       // log2 of the scale the main kernel carries its probabilities at
 
 template <int NPASS>
@@ -273,6 +277,217 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
 }
 
 // ---------------------------------------------------------------------------------------------
+// Two-wave-group variant (8 waves, split precision): the matrix work and the softmax of a key tile run in DIFFERENT barrier
+// intervals, and the second wave group (waves 4-7) runs one interval behind the first. Waves w and w + 4 share a SIMD, so on
+// every SIMD one wave issues 48 MFMAs (O^T += V^T P^T of tile t-1, then S^T = K Q^T of tile t: an M segment) while its partner
+// does the ~250 VALU instructions of a softmax (an S segment) - the two pipes of a SIMD work at the same time by construction
+// instead of by the instruction scheduler's luck inside one wave (PMC of the lock-step kernel above: MFMA busy 0.37, VALU 0.27).
+//   G0: M(t) in interval 2t, S(t) in 2t+1        G1: M(t) in 2t+1, S(t) in 2t+2
+// K / V^T tiles live in 4-slot rings (128 KiB). M(t) reads K(t) and V(t-1); both slots are free once G1's M(t) is over, and
+// S(t) re-stages slot (t-1) % 4 of the K ring with K(t+3) and slot (t-2) % 4 of the V ring with V(t+2): at least two intervals
+// after the last read, and three (G1) to four (G0) intervals before M(t+3) needs them. One counted vmcnt per tile, placed
+// before the barrier in front of G0's M segment (G0: end of its S, two younger staging segments in flight; G1: end of its M, one).
+// Per-lane arithmetic and accumulation order are those of attn_kernel: the results are bit-identical.
+// ---------------------------------------------------------------------------------------------
+template <int NPASS>
+__global__ __launch_bounds__(512, 1) void attn_pp_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = 8, RD = 4;
+  if ((int)blockIdx.x >= p.main_blocks) { attn_tail_body<NPASS>(p, (int)blockIdx.x - p.main_blocks, smem); return; }
+  static_assert(NPASS == 3, "split precision only");
+  constexpr int PART = 64 * 128;
+  constexpr int SLOT = 2 * PART;
+  char* const Kring = smem;
+  char* const Vring = smem + RD * SLOT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int nqb = (p.Tq + 32 * NW - 1) / (32 * NW);
+  const int bid = xcd_remap(blockIdx.x, p.main_blocks);
+  const int bh = bid / nqb, qb = bid - bh * nqb;
+  const int b = bh / p.heads, head = bh - b * p.heads;
+  const int T = p.T;
+  const size_t qk_base = (size_t)bh * T * 64;
+  const size_t v_base = (size_t)bh * 64 * p.Tpad;
+  const int h = lane >> 5, r = lane & 31;
+
+  int q = qb * (32 * NW) + wave * 32 + r;
+  const bool q_ok = q < p.Tq;
+  if (!q_ok) q = T - 1;
+  half8 qh[4], ql[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    qh[s] = *(const half8*)(p.Qhi + qk_base + (size_t)q * 64 + 16 * s + 8 * h);
+    ql[s] = *(const half8*)(p.Qlo + qk_base + (size_t)q * 64 + 16 * s + 8 * h);
+  }
+  const int drow = wave * 8 + (lane >> 3);
+  const int dch = swz128(drow, lane & 7) * 8;
+  auto stageK = [&](int slot, int it) {
+    char* base = Kring + slot * SLOT + wave * 1024;
+    int key = it * 64 + drow; if (key > T - 1) key = T - 1;
+    const size_t o = qk_base + (size_t)key * 64 + dch;
+    glds16(p.Khi + o, base);
+    glds16(p.Klo + o, base + PART);
+  };
+  auto stageV = [&](int slot, int it) {
+    char* base = Vring + slot * SLOT + wave * 1024;
+    const size_t o = v_base + (size_t)drow * p.Tpad + it * 64 + dch;
+    glds16(p.Vhi + o, base);
+    glds16(p.Vlo + o, base + PART);
+  };
+  f32x16 sc[2];
+  auto qk = [&](const char* kb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sc[i][e] = 0.f;
+      const int row = 32 * i + r;
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const int off = row * 128 + swz128(row, 2 * st + h) * 16;
+        const half8 kh = *(const half8*)(kb + off);
+        const half8 kl = *(const half8*)(kb + PART + off);
+        sc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[st], sc[i], 0, 0, 0);
+        sc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[st], sc[i], 0, 0, 0);
+        sc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[st], sc[i], 0, 0, 0);
+      }
+    }
+  };
+  f32x16 o0[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o0[t][i] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  half8 ph[2][2], pl[2][2];
+  auto pv = [&](const char* vb) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = 32 * t + r;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+          const int off = row * 128 + swz128(row, 4 * i + 2 * sp + h) * 16;
+          const half8 vh = *(const half8*)(vb + off);
+          const half8 vl = *(const half8*)(vb + PART + off);
+          o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[i][sp], o0[t], 0, 0, 0);
+          o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[i][sp], o0[t], 0, 0, 0);
+          o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[i][sp], o0[t], 0, 0, 0);
+        }
+    }
+  };
+  // softmax of the scores in sc (tile it): probabilities into ph / pl, running max / sum, O rescaled
+  auto softmax = [&](int it, bool last) {
+    if (last) {
+      const int kbase = it * 64;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = kbase + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (key >= T) sc[i][e] = -1e30f;
+        }
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sc[i][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 shift2 = {kPShift - m_new, kPShift - m_new};
+    f32x2 psum2 = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          f32x2 d = {sc[i][8 * sp + e], sc[i][8 * sp + e + 1]};
+          d += shift2;
+          f32x2 pvv = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+          psum2 += pvv;
+          const half_t h0 = (half_t)pvv[0], h1 = (half_t)pvv[1];
+          ph[i][sp][e] = h0; ph[i][sp][e + 1] = h1;
+          const f32x2 hf = {(float)h0, (float)h1};
+          const f32x2 pd = pvv - hf;
+          pl[i][sp][e] = (half_t)pd[0]; pl[i][sp][e + 1] = (half_t)pd[1];
+        }
+      }
+    const float psum = psum2[0] + psum2[1];
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o0[t][e] *= alpha;
+  };
+#define OVM_PBAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+  const int nt = (T + 63) >> 6;
+  // prologue: the first four K and V^T tiles
+#pragma unroll
+  for (int i = 0; i < RD; ++i) {
+    if (i < nt) { stageK(i, i); stageV(i, i); }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  OVM_PBAR();
+  if (grp == 1) OVM_PBAR();                             // G1 runs one interval behind G0
+  qk(Kring);                                            // M(0): scores of tile 0
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  OVM_PBAR();
+  for (int t = 0; t < nt; ++t) {
+    // ---- S(t)
+    int issued = 0;                                     // pieces this wave issues in this segment (wave-uniform)
+    if (t >= 1 && t - 1 + RD < nt) { stageK((t - 1) & (RD - 1), t - 1 + RD); issued += 2; }
+    if (t >= 2 && t - 2 + RD < nt) { stageV((t - 2) & (RD - 1), t - 2 + RD); issued += 2; }
+    softmax(t, t == nt - 1);
+    if (grp == 0) {
+      // K(t+1) / V(t) were staged two S segments ago; what S(t-1) and S(t) issued may stay in flight
+      const int prev = ((t >= 2 && t - 2 + RD < nt) ? 2 : 0) + ((t >= 3 && t - 3 + RD < nt) ? 2 : 0);   // issued by S(t-1)
+      const int allow = issued + prev;
+      if (allow >= 8) wait_vmcnt_n<8>(); else if (allow >= 6) wait_vmcnt_n<6>(); else if (allow >= 4) wait_vmcnt_n<4>();
+      else if (allow >= 2) wait_vmcnt_n<2>(); else wait_vmcnt_n<0>();
+    }
+    OVM_PBAR();
+    // ---- M(t+1): O^T += V^T(t) P^T(t), then the scores of tile t+1
+    pv(Vring + (t & (RD - 1)) * SLOT);
+    if (t + 1 < nt) qk(Kring + ((t + 1) & (RD - 1)) * SLOT);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (grp == 1) {
+      // before the barrier in front of G0's M(t+2): K(t+2) / V(t+1) were staged in S(t-1); S(t) may stay in flight
+      if (issued >= 4) wait_vmcnt_n<4>(); else if (issued >= 2) wait_vmcnt_n<2>(); else wait_vmcnt_n<0>();
+    }
+    OVM_PBAR();
+  }
+  if (grp == 0) OVM_PBAR();                             // same number of barriers for every wave
+#undef OVM_PBAR
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (q_ok) {
+    const size_t orow = ((size_t)b * T + q) * p.ldo + (p.o_il ? head * 128 : head * 64);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        half4 hv, lv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          half_t hh, ll; split_f16(o0[t][4 * g + e] * inv, hh, ll); hv[e] = hh; lv[e] = ll;
+        }
+        const int d = 32 * t + 8 * g + 4 * h;
+        const int oc = p.o_il ? il_col(d) : d;
+        *(half4*)(p.Ohi + orow + oc) = hv;
+        if (p.Olo) *(half4*)(p.Olo + orow + oc) = lv;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Tail query rows. T = 4097 leaves ONE query past 32 blocks of 128; as a 33rd block per head it would
 // add a second, nearly empty round of workgroups. Up to 8 leftover queries per (batch, head) are handled by
 // extra workgroups of the same launch instead: scores and probabilities in LDS, fp32 FMAs on the
@@ -370,6 +585,8 @@ static int g_attn_tail = 1;
 void attn_set_tail_rows(int on) { g_attn_tail = on; }
 static int g_attn_lds_pad = 0;      // experiment: extra dynamic LDS per workgroup (lowers workgroups per CU)
 void attn_set_lds_pad(int v) { g_attn_lds_pad = v; }
+static int g_attn_pp = 1;           // two-wave-group kernel for the 8-wave split-precision case (ovm_tune_set "attn_pp")
+void attn_set_pp(int v) { g_attn_pp = v; }
 static int g_attn_waves = 0;        // 0 = automatic (8 by default, 4 in co-run mode)
 void attn_set_waves(int v) { g_attn_waves = (v == 4 || v == 8) ? v : 0; }
 
@@ -398,7 +615,12 @@ int launch_attention(const AttnParams& p, int npass, hipStream_t s) {
   const int pad = g_attn_lds_pad;                  // experiment knob; the 3-slot rings (96 KB) already keep a workgroup alone on its CU
   if (npass == 3) {
     const int smem = OVM_ATTN_RD * 4 * 64 * 128 + pad;
-    if (nw == 8) {
+    if (nw == 8 && g_attn_pp) {
+      constexpr int smem_pp = 2 * 4 * 2 * 64 * 128;        // two 4-slot rings of hi + lo tiles = 128 KiB
+      static bool setpp = false;
+      if (!setpp) { (void)hipFuncSetAttribute((const void*)attn_pp_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); setpp = true; }
+      hipLaunchKernelGGL((attn_pp_kernel<3>), grid, block, smem_pp + pad, s, pm);
+    } else if (nw == 8) {
       static bool set8 = false;
       if (!set8) { (void)hipFuncSetAttribute((const void*)attn_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set8 = true; }
       hipLaunchKernelGGL((attn_kernel<3, 8>), grid, block, smem, s, pm);

@@ -75,6 +75,7 @@ int launch_attention(const AttnParams& p, int npass, hipStream_t s);
 void attn_set_tail_rows(int on);
 void attn_set_lds_pad(int v);
 void attn_set_waves(int v);
+void attn_set_pp(int v);
 int launch_roi_align(const RoiParams& p, hipStream_t s);
 int launch_cube_decode(const CubeDecodeParams& p, hipStream_t s);
 int launch_compact_records(const float* rec, const int* keep, int n, int B, float* out, int* counts, hipStream_t s);

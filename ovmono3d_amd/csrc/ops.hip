@@ -193,6 +193,7 @@ int ovm_tune_set(const char* key, int32_t value) {
   if (!strcmp(key, "gemm_splitk")) { gemm_set_splitk(value); return OVM_OK; }
   if (!strcmp(key, "gemm_tail")) { gemm_set_tail_rows(value); return OVM_OK; }
   if (!strcmp(key, "attn_waves")) { attn_set_waves(value); return OVM_OK; }
+  if (!strcmp(key, "attn_pp")) { attn_set_pp(value); return OVM_OK; }
   if (!strcmp(key, "attn_lds_pad")) { attn_set_lds_pad(value); return OVM_OK; }
   if (!strcmp(key, "attn_tail")) { attn_set_tail_rows(value); return OVM_OK; }
   if (!strcmp(key, "glin_small_max_tiles")) { glinear_set_small_max_tiles(value); return OVM_OK; }

@@ -330,3 +330,27 @@ def test_gemm256_two_wave_group_kernel(device, M, N, K, ksplit):
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     finally:
         L.ovm_tune_set(b"op_gemm256", 0)
+
+
+@pytest.mark.parametrize("B,T,heads", [(1, 4097, 2), (2, 1370, 3), (1, 257, 2), (1, 5477, 1), (1, 300, 2)])
+def test_attention_two_wave_group_kernel_is_bit_identical(device, B, T, heads):
+    """attn_pp_kernel (matrix and softmax segments of the two wave groups in alternating barrier intervals, 4-slot K / V^T rings
+    re-staged under counted vmcnt waits) keeps attn_kernel's per-lane arithmetic and accumulation order: same bits, on ragged
+    last tiles (T % 64 = 1, 26, 37, 44), short sequences (fewer tiles than ring slots) and repeated launches."""
+    g = torch.Generator().manual_seed(T + heads)
+    qkv = (torch.randn(B * T, 3 * heads * 64, generator=g) * 1.5).to(device)
+    L = _lib()
+    outs = {}
+    try:
+        assert L.ovm_tune_set(b"attn_waves", 8) == 0
+        for pp in (0, 1, 1):
+            assert L.ovm_tune_set(b"attn_pp", pp) == 0
+            out = torch.full((B * T, heads * 64), float("nan"), device=device)
+            assert L.ovm_op_attention(qkv.data_ptr(), B, T, heads, out.data_ptr(), 3, _stream()) == 0
+            torch.cuda.synchronize()
+            outs.setdefault(pp, []).append(out)
+    finally:
+        L.ovm_tune_set(b"attn_waves", 0)
+        L.ovm_tune_set(b"attn_pp", 1)
+    assert_close(outs[1][0], _attn_ref(qkv.cpu(), B, T, heads), 3e-6, "two-wave-group attention")
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[1][0], outs[1][1])
