@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
 // before the barrier in front of G0's M segment (G0: end of its S, two younger staging segments in flight; G1: end of its M, one).
 // Per-lane arithmetic and accumulation order are those of attn_kernel: the results are bit-identical.
 // ---------------------------------------------------------------------------------------------
-template <int NPASS>
+template <int NPASS, int STAMP = 0>
 __global__ __launch_bounds__(512, 1) void attn_pp_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = 8, RD = 4;
@@ -336,23 +336,6 @@ __global__ __launch_bounds__(512, 1) void attn_pp_kernel(const AttnParams p) {
     glds16(p.Vlo + o, base + PART);
   };
   f32x16 sc[2];
-  auto qk = [&](const char* kb) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) sc[i][e] = 0.f;
-      const int row = 32 * i + r;
-#pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        const int off = row * 128 + swz128(row, 2 * st + h) * 16;
-        const half8 kh = *(const half8*)(kb + off);
-        const half8 kl = *(const half8*)(kb + PART + off);
-        sc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[st], sc[i], 0, 0, 0);
-        sc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[st], sc[i], 0, 0, 0);
-        sc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[st], sc[i], 0, 0, 0);
-      }
-    }
-  };
   f32x16 o0[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -360,21 +343,96 @@ __global__ __launch_bounds__(512, 1) void attn_pp_kernel(const AttnParams p) {
     for (int i = 0; i < 16; ++i) o0[t][i] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
   half8 ph[2][2], pl[2][2];
-  auto pv = [&](const char* vb) {
+  // Fragment offsets inside a 64-row slot part: row 32 j + r, 16-byte chunk c -> (32 j + r) * 128 + ((c ^ ((r >> 1) & 7)) << 4);
+  // the row-block term 4096 j and the lo part (+ PART) are immediates of the ds_read
+  int xk[4], xv[4];
+  {
+    const int x = (r >> 1) & 7;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int row = 32 * t + r;
+    for (int st = 0; st < 4; ++st) xk[st] = r * 128 + (((2 * st + h) ^ x) << 4);          // K: chunk 2 st + h
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int c = 0; c < 4; ++c) xv[c] = r * 128 + (((4 * (c >> 1) + 2 * (c & 1) + h) ^ x) << 4);   // V^T: chunk 4 i + 2 sp + h, c = 2 i + sp
+  }
+  // M segment: 8 double steps of {4 ds_read_b128, 6 MFMAs}. A double step advances TWO independent accumulators by one
+  // (hi, lo) fragment pair each - PV: O^T rows 0-31 and 32-63 (t = 0, 1; inside each the order i, sp of attn_kernel), then QK:
+  // keys 0-31 and 32-63 (i = 0, 1; order st) - with their MFMAs interleaved a, b, a, b, a, b: dependent v_mfma_f32_32x32x16_f16
+  // on one accumulator issue only every 64 cycles (stamps: 3100 cycles for a segment of 48 chained MFMAs), two interleaved chains
+  // run at the 32-cycle issue rate. The reads of double step d + 1 are issued in front of the MFMAs of d (two register sets).
+  // They are inline asm with hand-counted lgkmcnt waits (cdna_hip_programming.md 5.7, form iii): left to the compiler every wait
+  // here came out as lgkmcnt(0) directly behind the youngest read. LDS reads return in order: before the MFMAs of d exactly the
+  // four reads of d + 1 may be pending.
+// (diagnostic builds: STAMP 2 drops the fragment reads, STAMP 3 the MFMAs - timing-only ablations, results are wrong)
+#define OVM_DSR(DST, ADDR, OFF) do { if (STAMP != 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"(OFF)); \
+                                     else asm volatile("" : "=v"(DST) : "v"(ADDR)); } while (0)
+#define OVM_MF(A, B, C) (STAMP == 3 ? (C) : __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0))
+#define OVM_LGKM(N) do { asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N)); __builtin_amdgcn_sched_barrier(0); } while (0)
+  bool fine_stamp = false;                                      // diagnostic (STAMP 2): stamps inside one M segment
+  unsigned long long* stamp_lds = (unsigned long long*)(smem + 2 * RD * SLOT) + wave * 128;
+  auto m_segment = [&](unsigned vb, unsigned kb, auto qk_tag) {
+    constexpr bool QK = decltype(qk_tag)::value;
+    constexpr int ND = QK ? 8 : 4;
+    unsigned va[4], ka[4];
 #pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-          const int off = row * 128 + swz128(row, 4 * i + 2 * sp + h) * 16;
-          const half8 vh = *(const half8*)(vb + off);
-          const half8 vl = *(const half8*)(vb + PART + off);
-          o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[i][sp], o0[t], 0, 0, 0);
-          o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[i][sp], o0[t], 0, 0, 0);
-          o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[i][sp], o0[t], 0, 0, 0);
-        }
+    for (int j = 0; j < 4; ++j) { va[j] = vb + (unsigned)xv[j]; ka[j] = kb + (unsigned)xk[j]; }
+    half8 fh[2][2], fl[2][2];                                  // [set][chain a / b]
+    if (STAMP == 2 && fine_stamp && blockIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) stamp_lds[109] = t_; }
+    // double step d < 4: V^T slot, chunk set d (= 2 i + sp), row blocks 0 (a) and 1 (b); d >= 4: K slot, chunk set d - 4 (= st)
+#define OVM_RD(D)                                                                            \
+    do {                                                                                     \
+      if ((D) < 4) {                                                                         \
+        OVM_DSR(fh[(D) & 1][0], va[(D) & 3], 0); OVM_DSR(fl[(D) & 1][0], va[(D) & 3], 8192);             \
+        OVM_DSR(fh[(D) & 1][1], va[(D) & 3], 4096); OVM_DSR(fl[(D) & 1][1], va[(D) & 3], 4096 + 8192);   \
+      } else {                                                                               \
+        OVM_DSR(fh[(D) & 1][0], ka[(D) & 3], 0); OVM_DSR(fl[(D) & 1][0], ka[(D) & 3], 8192);             \
+        OVM_DSR(fh[(D) & 1][1], ka[(D) & 3], 4096); OVM_DSR(fl[(D) & 1][1], ka[(D) & 3], 4096 + 8192);   \
+      }                                                                                      \
+    } while (0)
+#define OVM_DSTEP(D)                                                                         \
+    if ((D) < ND) {                                                                          \
+      if ((D) + 1 < ND) { OVM_RD((D) + 1); OVM_LGKM(4); } else { OVM_LGKM(0); }              \
+      const half8 ah_ = fh[(D) & 1][0], al_ = fl[(D) & 1][0], bh_ = fh[(D) & 1][1], bl_ = fl[(D) & 1][1];  \
+      if ((D) < 4) {                                                                         \
+        constexpr int i_ = ((D) >> 1) & 1, sp_ = (D) & 1;                                    \
+        o0[0] = OVM_MF(al_, ph[i_][sp_], o0[0]);   \
+        o0[1] = OVM_MF(bl_, ph[i_][sp_], o0[1]);   \
+        o0[0] = OVM_MF(ah_, pl[i_][sp_], o0[0]);   \
+        o0[1] = OVM_MF(bh_, pl[i_][sp_], o0[1]);   \
+        o0[0] = OVM_MF(ah_, ph[i_][sp_], o0[0]);   \
+        o0[1] = OVM_MF(bh_, ph[i_][sp_], o0[1]);   \
+      } else {                                                                               \
+        constexpr int st_ = (D) & 3;                                                         \
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   \
+        sc[0] = OVM_MF(al_, qh[st_], st_ == 0 ? zero16 : sc[0]);  \
+        sc[1] = OVM_MF(bl_, qh[st_], st_ == 0 ? zero16 : sc[1]);  \
+        sc[0] = OVM_MF(ah_, ql[st_], sc[0]);       \
+        sc[1] = OVM_MF(bh_, ql[st_], sc[1]);       \
+        sc[0] = OVM_MF(ah_, qh[st_], sc[0]);       \
+        sc[1] = OVM_MF(bh_, qh[st_], sc[1]);       \
+      }                                                                                      \
+      if (STAMP == 3) asm volatile("" ::"v"(ah_), "v"(al_), "v"(bh_), "v"(bl_));          \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+      if (STAMP == 2 && fine_stamp && blockIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) stamp_lds[110 + (D)] = t_; } \
+    }
+    OVM_RD(0);
+    OVM_DSTEP(0) OVM_DSTEP(1) OVM_DSTEP(2) OVM_DSTEP(3) OVM_DSTEP(4) OVM_DSTEP(5) OVM_DSTEP(6) OVM_DSTEP(7)
+#undef OVM_DSTEP
+#undef OVM_RD
+  };
+  // scores of the first tile (M(0) has no previous tile)
+  auto qk_first = [&](const char* kb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sc[i][e] = 0.f;
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const char* a = kb + xk[st] + i * 4096;
+        const half8 kh = *(const half8*)a;
+        const half8 kl = *(const half8*)(a + PART);
+        sc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[st], sc[i], 0, 0, 0);
+        sc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[st], sc[i], 0, 0, 0);
+        sc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[st], sc[i], 0, 0, 0);
+      }
     }
   };
   // softmax of the scores in sc (tile it): probabilities into ph / pl, running max / sum, O rescaled
@@ -425,8 +483,14 @@ __global__ __launch_bounds__(512, 1) void attn_pp_kernel(const AttnParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) o0[t][e] *= alpha;
   };
-#define OVM_PBAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+  // STAMP = 1: diagnostic build (ovm_debug_set_ptr "attn_stamps"), workgroup 0 records s_memtime before and after every barrier
+  int stamp_i = 0;
+#define OVM_PSTAMP() do { if (STAMP && blockIdx.x == 0 && stamp_i < 100) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    if (lane == 0) stamp_lds[stamp_i] = t_; ++stamp_i; } } while (0)
+#define OVM_PBAR() do { __builtin_amdgcn_sched_barrier(0); OVM_PSTAMP(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); OVM_PSTAMP(); } while (0)
 
+  const int g_prio_mode = p.prio_mode;
+  if (g_prio_mode == 2 && grp == 1) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the younger wave group
   const int nt = (T + 63) >> 6;
   // prologue: the first four K and V^T tiles
 #pragma unroll
@@ -436,15 +500,25 @@ __global__ __launch_bounds__(512, 1) void attn_pp_kernel(const AttnParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   OVM_PBAR();
   if (grp == 1) OVM_PBAR();                             // G1 runs one interval behind G0
-  qk(Kring);                                            // M(0): scores of tile 0
+  qk_first(Kring);                                      // M(0): scores of tile 0
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   OVM_PBAR();
-  for (int t = 0; t < nt; ++t) {
+  // one tile step: S(t), barrier, M(t+1), barrier. LAST (the final tile, peeled out of the loop so that the loop body has one
+  // straight-line M segment and no phi copies of the score registers): masked ragged keys, PV only.
+  auto tile_step = [&](int t, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
     // ---- S(t)
     int issued = 0;                                     // pieces this wave issues in this segment (wave-uniform)
-    if (t >= 1 && t - 1 + RD < nt) { stageK((t - 1) & (RD - 1), t - 1 + RD); issued += 2; }
-    if (t >= 2 && t - 2 + RD < nt) { stageV((t - 2) & (RD - 1), t - 2 + RD); issued += 2; }
-    softmax(t, t == nt - 1);
+    if (!LAST) {
+      if (t >= 1 && t - 1 + RD < nt) { stageK((t - 1) & (RD - 1), t - 1 + RD); issued += 2; }
+      if (t >= 2 && t - 2 + RD < nt) { stageV((t - 2) & (RD - 1), t - 2 + RD); issued += 2; }
+    }
+    if (g_prio_mode == 1) __builtin_amdgcn_s_setprio(1);   // experiment: the VALU-heavy segment wins issue arbitration against the partner's MFMAs
+    softmax(t, LAST);
+    if (g_prio_mode == 1) __builtin_amdgcn_s_setprio(0);
+    // the row sums / maxima are complete HERE: without this the optimiser sinks the 16-deep dependent v_pk_add chain of the row
+    // sum (and its s_nops) below the barrier, behind the MFMAs of the M segment, where nothing overlaps it
+    asm volatile("" : "+v"(l_run), "+v"(m_run));
     if (grp == 0) {
       // K(t+1) / V(t) were staged two S segments ago; what S(t-1) and S(t) issued may stay in flight
       const int prev = ((t >= 2 && t - 2 + RD < nt) ? 2 : 0) + ((t >= 3 && t - 3 + RD < nt) ? 2 : 0);   // issued by S(t-1)
@@ -454,17 +528,26 @@ __global__ __launch_bounds__(512, 1) void attn_pp_kernel(const AttnParams p) {
     }
     OVM_PBAR();
     // ---- M(t+1): O^T += V^T(t) P^T(t), then the scores of tile t+1
-    pv(Vring + (t & (RD - 1)) * SLOT);
-    if (t + 1 < nt) qk(Kring + ((t + 1) & (RD - 1)) * SLOT);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // LDS byte addresses: the dynamic segment starts at offset 0 (no static __shared__ in this kernel)
+    fine_stamp = (t == 20);
+    const unsigned vb_ = (unsigned)(RD * SLOT) + (unsigned)((t & (RD - 1)) * SLOT), kb_ = (unsigned)(((t + 1) & (RD - 1)) * SLOT);
+    if (!LAST) m_segment(vb_, kb_, std::true_type{});
+    else m_segment(vb_, kb_, std::false_type{});
     if (grp == 1) {
       // before the barrier in front of G0's M(t+2): K(t+2) / V(t+1) were staged in S(t-1); S(t) may stay in flight
       if (issued >= 4) wait_vmcnt_n<4>(); else if (issued >= 2) wait_vmcnt_n<2>(); else wait_vmcnt_n<0>();
     }
     OVM_PBAR();
-  }
+  };
+#pragma clang loop unroll(disable)
+  for (int t = 0; t + 1 < nt; ++t) tile_step(t, std::false_type{});
+  tile_step(nt - 1, std::true_type{});
   if (grp == 0) OVM_PBAR();                             // same number of barriers for every wave
 #undef OVM_PBAR
+  if (STAMP && blockIdx.x == 0 && p.stamps) {
+    __syncthreads();
+    if (lane == 0) { for (int i = 0; i < 126; ++i) p.stamps[wave * 128 + i] = (i < stamp_i || i >= 109) ? stamp_lds[i] : 0ull; p.stamps[wave * 128 + 127] = stamp_i; }
+  }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
@@ -585,7 +668,12 @@ static int g_attn_tail = 1;
 void attn_set_tail_rows(int on) { g_attn_tail = on; }
 static int g_attn_lds_pad = 0;      // experiment: extra dynamic LDS per workgroup (lowers workgroups per CU)
 void attn_set_lds_pad(int v) { g_attn_lds_pad = v; }
-static int g_attn_pp = 1;           // two-wave-group kernel for the 8-wave split-precision case (ovm_tune_set "attn_pp")
+static unsigned long long* g_attn_stamps = nullptr;
+void attn_set_stamps(unsigned long long* p) { g_attn_stamps = p; }
+static int g_attn_prio = 0;
+void attn_set_prio(int v) { g_attn_prio = v; }
+static int g_attn_pp = 0;           // 1: two-wave-group kernel for the 8-wave split-precision case (ovm_tune_set "attn_pp"); measured equal
+                                    // to the lock-step kernel (6.36 vs 6.23 ms per ViT-L image, same box), so it stays an option
 void attn_set_pp(int v) { g_attn_pp = v; }
 static int g_attn_waves = 0;        // 0 = automatic (8 by default, 4 in co-run mode)
 void attn_set_waves(int v) { g_attn_waves = (v == 4 || v == 8) ? v : 0; }
@@ -595,6 +683,8 @@ int launch_attention(const AttnParams& p, int npass, hipStream_t s) {
   if (p.Tpad % 64 != 0 || p.Tpad < ((p.T + 63) / 64) * 64) return OVM_ERR_SHAPE;
   if (npass == 3 && (!p.Qlo || !p.Klo || !p.Vlo)) return OVM_ERR_INVALID;
   AttnParams pm = p;
+  pm.stamps = g_attn_stamps;
+  pm.prio_mode = g_attn_prio;
   // Default: 8-wave workgroups - 256 queries share one K / V^T tile stream, i.e. half the LDS-DMA traffic of two 4-wave
   // workgroups per CU at the same 2 waves per SIMD (7.6 -> 6.7 ms per ViT-L image). Co-run mode (another stream's short kernels
   // run beside this launch): ONE 4-wave workgroup per CU; that kernel is slower by itself
@@ -619,6 +709,14 @@ int launch_attention(const AttnParams& p, int npass, hipStream_t s) {
       constexpr int smem_pp = 2 * 4 * 2 * 64 * 128;        // two 4-slot rings of hi + lo tiles = 128 KiB
       static bool setpp = false;
       if (!setpp) { (void)hipFuncSetAttribute((const void*)attn_pp_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); setpp = true; }
+      if (pm.stamps) {
+        (void)hipFuncSetAttribute((const void*)attn_pp_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_pp_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_pp_kernel<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (g_attn_pp == 2) hipLaunchKernelGGL((attn_pp_kernel<3, 2>), grid, block, smem_pp + 8192, s, pm);
+        else if (g_attn_pp == 3) hipLaunchKernelGGL((attn_pp_kernel<3, 3>), grid, block, smem_pp + 8192, s, pm);
+        else hipLaunchKernelGGL((attn_pp_kernel<3, 1>), grid, block, smem_pp + 8192, s, pm);
+      } else
       hipLaunchKernelGGL((attn_pp_kernel<3>), grid, block, smem_pp + pad, s, pm);
     } else if (nw == 8) {
       static bool set8 = false;

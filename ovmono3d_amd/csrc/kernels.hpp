@@ -25,6 +25,8 @@ struct AttnParams {
   int B, heads, T, Tpad;
   int corun;                                         // another stream's short kernels run beside this launch: keep to one workgroup per CU
   int Tq, main_blocks;                               // set by the launcher: queries / workgroups of the tiled part
+  int prio_mode;                                     // experiment knob of the two-wave-group kernel (ovm_tune_set "attn_prio")
+  unsigned long long* stamps;                        // diagnostic build of the two-wave-group kernel: s_memtime per barrier, [8 waves][128]
 };
 
 struct RoiParams {
@@ -76,6 +78,8 @@ void attn_set_tail_rows(int on);
 void attn_set_lds_pad(int v);
 void attn_set_waves(int v);
 void attn_set_pp(int v);
+void attn_set_prio(int v);
+void attn_set_stamps(unsigned long long* p);
 int launch_roi_align(const RoiParams& p, hipStream_t s);
 int launch_cube_decode(const CubeDecodeParams& p, hipStream_t s);
 int launch_compact_records(const float* rec, const int* keep, int n, int B, float* out, int* counts, hipStream_t s);

@@ -194,6 +194,7 @@ int ovm_tune_set(const char* key, int32_t value) {
   if (!strcmp(key, "gemm_tail")) { gemm_set_tail_rows(value); return OVM_OK; }
   if (!strcmp(key, "attn_waves")) { attn_set_waves(value); return OVM_OK; }
   if (!strcmp(key, "attn_pp")) { attn_set_pp(value); return OVM_OK; }
+  if (!strcmp(key, "attn_prio")) { attn_set_prio(value); return OVM_OK; }
   if (!strcmp(key, "attn_lds_pad")) { attn_set_lds_pad(value); return OVM_OK; }
   if (!strcmp(key, "attn_tail")) { attn_set_tail_rows(value); return OVM_OK; }
   if (!strcmp(key, "glin_small_max_tiles")) { glinear_set_small_max_tiles(value); return OVM_OK; }
@@ -209,6 +210,7 @@ int ovm_tune_set(const char* key, int32_t value) {
 /* diagnostics: hands a device pointer to a named debug hook ("gemm256_stamps": u64 [8][128], NULL switches it off) */
 int ovm_debug_set_ptr(const char* key, void* ptr) {
   if (key && !strcmp(key, "gemm256_stamps")) { g_gemm256_stamps = (unsigned long long*)ptr; return OVM_OK; }
+  if (key && !strcmp(key, "attn_stamps")) { attn_set_stamps((unsigned long long*)ptr); return OVM_OK; }
   return OVM_ERR_INVALID;
 }
 

@@ -351,6 +351,6 @@ def test_attention_two_wave_group_kernel_is_bit_identical(device, B, T, heads):
             outs.setdefault(pp, []).append(out)
     finally:
         L.ovm_tune_set(b"attn_waves", 0)
-        L.ovm_tune_set(b"attn_pp", 1)
+        L.ovm_tune_set(b"attn_pp", 0)
     assert_close(outs[1][0], _attn_ref(qkv.cpu(), B, T, heads), 3e-6, "two-wave-group attention")
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[1][0], outs[1][1])
