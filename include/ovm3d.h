@@ -237,11 +237,24 @@ int ovm_gdino_forward(OvmGdino* g, const OvmImage* image, const int32_t* token_i
 int ovm_gdino_detect(OvmGdino* g, const OvmImage* image, const int32_t* token_ids, int32_t ntok, const int32_t* spans, int32_t n_phrases,
                      float box_threshold, float nms_threshold, float* out_boxes, float* out_scores, int32_t* out_classes, int32_t* n_out,
                      ovm_stream_t stream);
+int32_t ovm_gdino_num_queries(const OvmGdino* g);
+/* device pointers of the last forward's raw outputs (owned by the handle; valid until its next forward); logits_ld = max_text_len */
+int ovm_gdino_last_outputs(OvmGdino* g, const float** pred_logits, const float** pred_boxes, int32_t* logits_ld);
 /* tests: pin the two-stage top-k selection to the given device int32 [num_queries] (NULL: the network's own) */
 int ovm_gdino_set_force_topk(OvmGdino* g, const int32_t* idx_device);
 /* tests: copy an intermediate of the last forward ("bert_out", "text_features", "swin_stage1..3", "enc_vision", "enc_text",
  * "topk" (int32), "init_ref") into dst; returns the element count. name "launches": returns the kernel launches per forward. */
 int64_t ovm_gdino_debug_copy(OvmGdino* g, const char* name, void* dst, int64_t capacity_elems, ovm_stream_t stream);
+
+/* --- the whole path for one image as ONE call (SURVEY.md 8b `ovm_infer`): RCNN3D.inference with the text-prompted head, reference
+ * cubercnn/modeling/meta_arch/rcnn3d.py:79-117 (batched_inputs = [{image, height, width, K, category_list}]) ->
+ * roi_heads_gdino.py:93-171 -> roi_heads.py:329-549,798-848 -> detector_postprocess. `image` as for ovm_backbone_forward (orig
+ * size and K filled); token_ids / spans as for ovm_gdino_detect (spans[k] = [begin, end) token positions of category k's phrase,
+ * so the record's `category` is the index into the category list, roi_heads_gdino.py:162). out: device records, capacity
+ * out_capacity (<= the detector's num_queries are produced); n_out: host. Synchronises the stream. */
+int ovm_infer(OvmHandle* h, OvmGdino* g, const OvmImage* image, const int32_t* token_ids, int32_t ntok, const int32_t* spans,
+              int32_t n_phrases, float box_threshold, float nms_threshold, OvmDet3D* out, int32_t out_capacity, int32_t* n_out,
+              ovm_stream_t stream);
 
 /* --- generic device ops the GroundingDINO branch (ROIHeads3DGDINO's network, reference roi_heads_gdino.py:186) is
  * was sequenced from in round 1 (still exported: unit tests and the Python-sequenced cross-check path use them): fp32

@@ -283,6 +283,8 @@ def get_cfg_defaults(cfg: CfgNode) -> CfgNode:
                                  # co-run mode: throttle the ViT attention to one 4-wave workgroup per CU while the detector runs beside it
                                  # (0 to +6 % images/s end to end depending on the box; the attention kernel itself runs 1.4x slower: off by default)
                                  GDINO_CORUN=False,
+                                 # one image + category_list: the whole path as ONE C call (ovm_infer) instead of staged calls from Python
+                                 FUSED_INFER=True,
                                  # ResizeShortestEdge on the device (bit-identical to the host's Pillow resize)
                                  GPU_RESIZE=True))
     return cfg

@@ -71,6 +71,10 @@ struct OvmHandle {
   bool corun = false;               // ovm_set_corun
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[OVM_PROF_NCAT];
   size_t prof_used[OVM_PROF_NCAT] = {0};
+  // ovm_infer: side stream of the text-prompted detector + 2D detection buffers (capacity = the detector's query count)
+  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  float *inf_boxes = nullptr, *inf_scores = nullptr; int *inf_classes = nullptr, *inf_n = nullptr, *inf_idx = nullptr, *inf_counts = nullptr;
+  int inf_cap = 0;
 };
 
 namespace {
@@ -324,6 +328,9 @@ int ovm_destroy(OvmHandle* h) {
   if (h->h_meta) hipHostFree(h->h_meta);
   for (int c = 0; c < OVM_PROF_NCAT; ++c)
     for (auto& pr : h->prof_ev[c]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  if (h->ev_fork) hipEventDestroy(h->ev_fork);
+  if (h->ev_join) hipEventDestroy(h->ev_join);
+  if (h->side) hipStreamDestroy(h->side);
   delete h;
   return OVM_OK;
 }
@@ -720,6 +727,61 @@ int ovm_rpn_box_forward(OvmHandle* h, const OvmImage* images, int32_t B, float* 
   m.roi = rp; m.RF = {h->RF.hi, h->RF.lo}; m.H1 = {h->H1.hi, h->H1.lo}; m.H2 = {h->H2.hi, h->H2.lo}; m.HO = h->HO;
   int r = det2d_forward(m, h->det, boxes, scores, classes, image_idx, scores_full, out_counts, s);
   if (r) { h->err = "det2d_forward failed (" + std::to_string(r) + ")"; return r; }
+  return OVM_OK;
+}
+
+// RCNN3D.inference for ONE image with the text-prompted head, as one call (SURVEY.md 8b `ovm_infer`; reference
+// cubercnn/modeling/meta_arch/rcnn3d.py:79-117 with `category_list`: preprocess -> DINOv2 + SFP -> ROIHeads3DGDINO (GroundingDINO
+// network, phrase scores, threshold, NMS, class index: roi_heads_gdino.py:93-171) -> _forward_cube -> detector_postprocess).
+// The detector runs on an internal side stream beside the backbone (it reads only the input image); the caller's stream joins it
+// before the output glue. One host synchronisation (the number of kept 2D boxes sizes the cube-head launch).
+int ovm_infer(OvmHandle* h, OvmGdino* g, const OvmImage* image, const int32_t* token_ids, int32_t ntok, const int32_t* spans,
+              int32_t n_phrases, float box_threshold, float nms_threshold, OvmDet3D* out, int32_t out_capacity, int32_t* n_out,
+              ovm_stream_t stream) {
+  if (!h || !g || !image || !token_ids || !out || !n_out) return OVM_ERR_INVALID;
+  h->err.clear();
+  hipStream_t s = (hipStream_t)stream;
+  HCHECK(h, hipSetDevice(h->device));
+  if (!h->side) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    HCHECK(h, hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi));      // short kernels: let them jump the ViT's queue
+    HCHECK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HCHECK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  }
+  const int nq = ovm_gdino_num_queries(g);
+  if (nq <= 0) { h->err = "bad detector handle"; return OVM_ERR_INVALID; }
+  if (nq > h->cfg.max_rois * h->cfg.max_batch) { h->err = "detector queries exceed max_rois"; return OVM_ERR_CAPACITY; }
+  if (h->inf_cap < nq) {
+    int r;
+    if ((r = dalloc(h, &h->inf_boxes, (size_t)nq * 4)) || (r = dalloc(h, &h->inf_scores, (size_t)nq)) || (r = dalloc(h, &h->inf_classes, (size_t)nq)) ||
+        (r = dalloc(h, &h->inf_idx, (size_t)nq, true)) || (r = dalloc(h, &h->inf_n, 1)) || (r = dalloc(h, &h->inf_counts, 1))) return r;
+    h->inf_cap = nq;
+  }
+  // fork: detector on the side stream
+  HCHECK(h, hipEventRecord(h->ev_fork, s));
+  HCHECK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+  int r = ovm_gdino_forward(g, image, token_ids, ntok, nullptr, nullptr, nullptr, (ovm_stream_t)h->side);
+  if (r) { h->err = std::string("ovm_gdino_forward: ") + ovm_gdino_last_error(g); return r; }
+  HCHECK(h, hipEventRecord(h->ev_join, h->side));
+  // backbone on the caller's stream
+  r = ovm_backbone_forward(h, image, 1, nullptr, 0, 0, nullptr, nullptr, nullptr, stream);
+  if (r) return r;
+  // join, output glue (synchronises the stream), cube head
+  HCHECK(h, hipStreamWaitEvent(s, h->ev_join, 0));
+  const float *logits = nullptr, *gboxes = nullptr; int ld = 0;
+  r = ovm_gdino_last_outputs(g, &logits, &gboxes, &ld);
+  if (r) { h->err = "detector outputs unavailable"; return r; }
+  r = ovm_gdino_postprocess(logits, nq, ld, gboxes, spans, n_phrases, image->height, image->width, box_threshold, nms_threshold, h->inf_boxes,
+                            h->inf_scores, h->inf_classes, h->inf_n, stream);
+  if (r) { h->err = "ovm_gdino_postprocess failed"; return r; }
+  int n2d = 0;
+  HCHECK(h, hipMemcpy(&n2d, h->inf_n, sizeof(int), hipMemcpyDeviceToHost));
+  if (n2d > out_capacity) { h->err = "output capacity too small"; return OVM_ERR_CAPACITY; }
+  r = ovm_cube_forward(h, image, 1, h->inf_boxes, h->inf_scores, h->inf_classes, h->inf_idx, n2d, 1, out, h->inf_counts, stream);
+  if (r) return r;
+  HCHECK(h, hipMemcpyAsync(n_out, h->inf_counts, sizeof(int), hipMemcpyDeviceToHost, s));
+  HCHECK(h, hipStreamSynchronize(s));
   return OVM_OK;
 }
 

@@ -1176,6 +1176,17 @@ int ovm_gdino_detect(OvmGdino* g, const OvmImage* image, const int32_t* token_id
                                image->width, box_threshold, nms_threshold, out_boxes, out_scores, out_classes, n_out, stream);
 }
 
+int32_t ovm_gdino_num_queries(const OvmGdino* g) { return g ? g->cfg.num_queries : 0; }
+
+// device pointers of the last forward's raw outputs (owned by the handle's current plan; valid until the next forward)
+int ovm_gdino_last_outputs(OvmGdino* g, const float** pred_logits, const float** pred_boxes, int32_t* logits_ld) {
+  if (!g || !g->last) return OVM_ERR_INVALID;
+  if (pred_logits) *pred_logits = g->last->out_logits;
+  if (pred_boxes) *pred_boxes = g->last->out_boxes;
+  if (logits_ld) *logits_ld = g->cfg.max_text_len;
+  return OVM_OK;
+}
+
 int64_t ovm_gdino_debug_copy(OvmGdino* g, const char* name, void* dst, int64_t capacity_elems, ovm_stream_t stream) {
   if (!g || !g->last || !name) return OVM_ERR_INVALID;
   if (std::string(name) == "launches") return g->launches_last;

@@ -64,7 +64,7 @@ EXPORTS = [
     "ovm_g_pack_weight", "ovm_g_linear", "ovm_g_layernorm", "ovm_g_bmm", "ovm_g_bmm2", "ovm_g_softmax", "ovm_g_softmax2", "ovm_g_eltwise", "ovm_g_gather_rows",
     "ovm_g_groupnorm", "ovm_g_msdeform", "ovm_g_sine_embed", "ovm_g_normalize_image", "ovm_g_topk", "ovm_g_rowmax",
     "ovm_gdino_create", "ovm_gdino_destroy", "ovm_gdino_last_error", "ovm_gdino_forward", "ovm_gdino_detect", "ovm_gdino_set_force_topk",
-    "ovm_gdino_debug_copy", "ovm_debug_set_ptr",
+    "ovm_gdino_debug_copy", "ovm_debug_set_ptr", "ovm_gdino_num_queries", "ovm_gdino_last_outputs", "ovm_infer",
 ]
 PROF_NAMES = ("attn", "qkv", "proj", "fc1", "fc2", "ln")
 
@@ -140,6 +140,9 @@ def load() -> C.CDLL:
     lib.ovm_gdino_set_force_topk.argtypes = [vp, vp]
     lib.ovm_gdino_debug_copy.argtypes = [vp, C.c_char_p, vp, i64, vp]
     lib.ovm_gdino_debug_copy.restype = i64
+    lib.ovm_gdino_num_queries.argtypes = [vp]
+    lib.ovm_gdino_last_outputs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32)]
+    lib.ovm_infer.argtypes = [vp, vp, C.POINTER(OvmImage), C.POINTER(i32), i32, C.POINTER(i32), i32, f32, f32, vp, i32, C.POINTER(i32), vp]
     for name in EXPORTS:
         if name not in ("ovm_last_error", "ovm_version", "ovm_debug_copy", "ovm_gdino_last_error", "ovm_gdino_debug_copy"):
             getattr(lib, name).restype = i32

@@ -86,6 +86,9 @@ class RCNN3D:
         im_scales_ratio = [info["height"] / s[0] for info, s in zip(batched_inputs, images.image_sizes)]   # :92
         Ks = [torch.FloatTensor(np.asarray(info["K"], dtype=np.float32)) for info in batched_inputs]      # :95
         images.fuse_postprocess = bool(do_postprocess)
+        fused = self._infer_fused(batched_inputs, images, prompt_depth, do_postprocess)
+        if fused is not None:
+            return fused
         if hasattr(self.roi_heads, "prefetch") and "oracle2D" not in batched_inputs[0] and "category_list" in batched_inputs[0]:
             self.roi_heads.prefetch(images, batched_inputs[0]["category_list"])       # side stream, overlaps the backbone
         features = self.backbone(images, prompt_depth=prompt_depth)                                        # :97
@@ -102,6 +105,46 @@ class RCNN3D:
         if do_postprocess:
             return self._postprocess(results, batched_inputs, images.image_sizes)
         return results
+
+    def _infer_fused(self, batched_inputs, images, prompt_depth, do_postprocess):
+        """The text-prompted path as ONE C call (``ovm_infer``) when nothing needs the stages separately: ROIHeads3DGDINO with
+        the native engine as its detector, one image with a category_list, no depth prompt, post-processing on. Same kernels in
+        the same order as the staged path below (the detector beside the backbone on a side stream); returns None otherwise."""
+        rh = self.roi_heads
+        if not (do_postprocess and prompt_depth is None and len(batched_inputs) == 1 and hasattr(rh, "load_detector")
+                and bool(self.cfg.MODEL.AMD.get("FUSED_INFER", True)) and bool(self.cfg.MODEL.AMD.GDINO_OVERLAP)
+                and "oracle2D" not in batched_inputs[0] and batched_inputs[0].get("category_list")):
+            return None
+        if rh.detector is None:
+            rh.load_detector()
+        eng = getattr(rh.detector, "engine", None)
+        if eng is None or rh.loss_w_3d <= 0 or getattr(self.backbone, "export_features", False):
+            return None
+        from ..roi_heads.gdino_glue import build_caption, phrase_spans
+        cats = list(batched_inputs[0]["category_list"])
+        caption, cap_list = build_caption(cats)
+        ids, phrase_ids, _ = rh.detector._tokens(caption)
+        spans = phrase_spans(ids, phrase_ids)
+        rec, n = self.engine.infer_gdino(images.native, eng._h, ids, spans, 0.001, 0.5, eng.cfg.num_queries)   # roi_heads_gdino.py:148,254
+        # phrase k -> class index: filtered_texts.index([name]) of the reference (:162) = first occurrence of the caption's name
+        remap = [cats.index(c) if c in cats else -1 for c in cap_list]
+        if any(r < 0 for r in remap):
+            raise ValueError("category names must be lower-case / stripped for ROIHeads3DGDINO (reference roi_heads_gdino.py:162: "
+                             "filtered_texts.index([class_name]) raises for names that build_caption normalised)")
+        if remap != list(range(len(cap_list))) and n > 0:
+            cls = rec[:, 5].contiguous().view(torch.int32)
+            rec[:, 5] = torch.tensor(remap, dtype=torch.int32, device=rec.device)[cls.long()].view(torch.float32)
+        size = (int(images.native[0].orig_height), int(images.native[0].orig_width))
+        if n == 0:
+            from ...structures import Boxes, Instances
+            inst = Instances(images.image_sizes[0])             # roi_heads.py:371-372: no 3D fields; 2D instance untouched
+            inst.pred_boxes = Boxes(torch.zeros((0, 4), dtype=torch.float32))
+            inst.scores = torch.zeros(0)
+            inst.pred_classes = torch.zeros(0, dtype=torch.int64)
+            return [{"instances": inst}]
+        out = rh._instances_from_records(rec, [n], [size])
+        out[0]._postprocessed = True
+        return self._postprocess(out, batched_inputs, images.image_sizes)
 
     @staticmethod
     def _postprocess(instances, batched_inputs, image_sizes):

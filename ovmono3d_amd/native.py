@@ -211,6 +211,21 @@ class Engine:
         cl = counts.cpu().tolist()            # one D2H sync per batch (reference: omni3d_evaluation.py:669)
         return rec[: sum(cl)], cl
 
+    def infer_gdino(self, images, gdino_handle, token_ids: Sequence[int], spans: Sequence[Tuple[int, int]], box_threshold: float,
+                    nms_threshold: float, capacity: int):
+        """``ovm_infer``: preprocess -> backbone -> GroundingDINO engine (internal side stream) -> output glue -> cube head ->
+        postprocess for ONE image in one C call. Returns (records [n, 48], n)."""
+        self._require()
+        ids = (C.c_int32 * len(token_ids))(*[int(i) for i in token_ids])
+        flat = [int(v) for sp in spans for v in sp]
+        sp = (C.c_int32 * max(len(flat), 1))(*flat)
+        rec = torch.empty((max(capacity, 1), OVM_REC_FLOATS), dtype=torch.float32, device=self.device)
+        n = C.c_int32(0)
+        rc = self._lib.ovm_infer(self._h, gdino_handle, images, ids, len(token_ids), sp, len(spans), float(box_threshold), float(nms_threshold),
+                                 rec.data_ptr(), int(capacity), C.byref(n), self._stream())
+        check(rc, self._h, "ovm_infer")
+        return rec[: n.value], int(n.value)
+
     def set_corun(self, on: bool = True) -> None:
         """Other work runs on a second stream beside the backbone (ROIHeads3DGDINO's detector): attention keeps to one
         workgroup per CU so that stream's short kernels are not locked out. Scheduling only."""

@@ -142,3 +142,41 @@ def test_engine_full_size_swinb_matches_hf(device):
     torch.cuda.synchronize()
     print(f"C++ GroundingDINO engine, Swin-B {H}x{W}: {(time.time() - t0) / 10 * 1e3:.2f} ms per forward (graph replay), "
           f"{eng.launches()} kernel launches per forward")
+
+
+def test_ovm_infer_one_call_equals_staged_path(device):
+    """ovm_infer (the whole text-prompted path of one image behind ONE C-ABI call - backbone, GroundingDINO engine on
+    an internal side stream, output glue, cube head, postprocess) against the same stages sequenced by the Python host
+    (ROIHeads3DGDINO.prefetch / forward): identical records. Replaces reference rcnn3d.py:79-117 with category_list."""
+    from common import build_cfg, synth_inputs
+    from ovmono3d_amd.gdino.detector import HashTokenizer, NativeGroundingDino
+    from ovmono3d_amd.gdino.model import GDinoConfig
+    from ovmono3d_amd.modeling import build_model
+    from ovmono3d_amd.util.synth_weights import synth_state_dict
+    hf, _ = _small_hf_gdino()
+
+    class Tok(HashTokenizer):
+        def _id(self, w):
+            return super()._id(w) % 1900 + 50 if w not in (".", "?") else super()._id(w)
+    sd = synth_state_dict("vittest14", seed=3)
+    outs = []
+    for fused in (True, False):
+        cfg = build_cfg("vittest14", 280, "f16x3", max_batch=1, max_rois=64, roi_heads="ROIHeads3DGDINO", extra=["MODEL.AMD.FUSED_INFER", fused])
+        model = build_model(cfg, device=device)
+        model.load_state_dict(sd)
+        model.roi_heads.detector = NativeGroundingDino(device, hf.state_dict(), Tok(), cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD,
+                                                       cfg=GDinoConfig(**SMALL))
+        res = []
+        for seed in (5, 6, 5):                                   # second and third call replay the detector's graph
+            inp = synth_inputs(1, hw=((210, 280),), oracle2d=False, seed=seed)
+            inp[0]["category_list"] = ["chair", "dining table", "sofa"]
+            inp[0]["image"] = inp[0]["image"].to(device)
+            res.append(model(inp)[0]["instances"])
+        outs.append(res)
+    for a, b in zip(*outs):
+        assert len(a) == len(b) and len(a) >= 5
+        assert torch.equal(a.pred_classes.cpu(), b.pred_classes.cpu())
+        for f in ("scores", "pred_bbox3D", "pred_center_cam", "pred_center_2D", "pred_dimensions", "pred_pose"):
+            assert torch.equal(a.get(f), b.get(f)), f
+        assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor)
+    assert torch.equal(outs[0][0].pred_bbox3D, outs[0][2].pred_bbox3D)      # same input -> same output across graph replays
