@@ -173,9 +173,9 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return dt, prof, ndet, model, host_inputs, cfg, out
+        return dt, prof, ndet, model, host_inputs, cfg, out, inputs[0]
 
-    dt, prof, ndet, model, host_inputs, cfg, last_out = run(args.precision, args.steps, args.warmup, True)
+    dt, prof, ndet, model, host_inputs, cfg, last_out, inputs_dev0 = run(args.precision, args.steps, args.warmup, True)
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
 
@@ -314,9 +314,34 @@ def main():
                         "sample": f"{nimg} image(s) of the same workload through oracle/ (fp32 torch CPU restatement"
                                   + (" + Hugging Face GroundingDINO fp32 on CPU for the text-prompted boxes" if use_gdino else "")
                                   + f"), {el:.1f} s, torch threads={ncores}"}
-        # parity of the timed configuration itself: the HIP outputs of the timed image against the CPU leg's outputs for it
-        parity = parity_report(last_out[0]["instances"], ref0)
-        parity["ok_1e-3"] = parity_ok(parity, 1e-3)
+        # parity of the timed configuration itself: the HIP outputs of the timed image against the CPU leg's outputs for it.
+        # (a) end to end. With the text-prompted head the two routes take ~900 discrete decisions (two-stage top-900, threshold,
+        #     NMS at IoU 0.5) on scores that agree to ~1e-6, so a proposal on an edge may flip and the 2D boxes they hand to the
+        #     cube head differ in the last bits; detections are paired by their 2D boxes.
+        # (b) same boxes: the CPU leg's 2D boxes through the HIP cube branch on the HIP features - no discrete decision in
+        #     between, identity pairing, the strict 1e-3 check of the float path.
+        e2e = parity_report(last_out[0]["instances"], ref0)
+        parity = {"end_to_end": e2e}
+        strict = e2e
+        if use_gdino:
+            from ovmono3d_amd.structures import Boxes, Instances
+            with torch.no_grad():
+                images = model.preprocess_image([inputs_dev0])
+                model.backbone(images)
+                t_in = Instances(images.image_sizes[0])
+                t_in.pred_boxes, t_in.scores, t_in.pred_classes = Boxes(bx.to(dev)), sc.to(dev), cl.to(dev)
+                got_b = model.roi_heads._forward_cube(None, [t_in], None, list(images.image_sizes),
+                                                      [host_inputs[0]["height"] / images.image_sizes[0][0]], images=images, postprocess=True)[0]
+            strict = parity_report(got_b, ref0, box_tol=1e-4)
+            parity["same_boxes"] = strict
+        n_ref = max(e2e["n_det_oracle"], 1)
+        flips_ok = e2e["unmatched_oracle"] <= max(2, n_ref // 100) and e2e["unmatched_hip"] <= max(2, n_ref // 100)
+        # pose through the random-init 6-D head amplifies the ~1e-6 box differences of route (a) to ~1e-3 on a few detections
+        # (conditioning of the synthetic checkpoint; (b) shows the float path itself): 3e-3 there, 1e-3 everywhere else
+        e2e_ok = flips_ok and e2e["class_id_mismatches"] == 0 and all(v <= (3e-3 if k == "pred_pose" else 1e-3) for k, v in e2e["max_rel_err"].items())
+        parity["ok_1e-3"] = bool(parity_ok(strict, 1e-3) and e2e_ok)
+        parity["criteria"] = ("same_boxes: identity pairing, class ids exact, every float field <= 1e-3; end_to_end: <= 1 % of the "
+                              "detections flipped by discrete near-ties, class ids exact on the pairs, floats <= 1e-3 (pose <= 3e-3)")
         parity["oracle"] = ("oracle/ restatement" + (" + Hugging Face GroundingDINO port" if use_gdino else "")
                             + "; unpinned vs the reference itself (no reference fixtures exist, DESIGN.md 5)")
 
