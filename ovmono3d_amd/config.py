@@ -195,6 +195,14 @@ def get_cfg_defaults(cfg: CfgNode) -> CfgNode:
     Inference-relevant defaults only; cluster-specific absolute paths of the fork (:71,:76) are dropped."""
     cfg.DATASETS.CATEGORY_NAMES = []
     cfg.DATASETS.IGNORE_NAMES = []
+    # when a known box counts as ignore (too truncated / barely visible / too small / too far), and which 2D box is loaded
+    # (reference config.py:19-34); they feed evaluation/omni3d_gt.py
+    cfg.DATASETS.TRUNCATION_THRES = 0.99
+    cfg.DATASETS.VISIBILITY_THRES = 0.01
+    cfg.DATASETS.MIN_HEIGHT_THRES = 0.00
+    cfg.DATASETS.MAX_DEPTH = 1e8
+    cfg.DATASETS.MODAL_2D_BOXES = False
+    cfg.DATASETS.TRUNC_2D_BOXES = True
     cfg.DATASETS.TEST_BASE = ("Objectron_test",)
     cfg.DATASETS.TEST_NOVEL = ()
     cfg.DATASETS.CATEGORY_NAMES_BASE = ("bicycle", "books", "bottle", "camera", "cereal box",

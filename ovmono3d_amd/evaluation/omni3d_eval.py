@@ -2,13 +2,17 @@
 
 Upstream Omni3D semantics of the reference's ``Omni3Deval`` (cubercnn/evaluation/omni3d_evaluation.py):
 ``Omni3DParams`` :1394-1461 (2D: IoU 0.5:0.05:0.95, area ranges; 3D: IoU 0.05:0.05:0.50, depth ranges [0,10,35,1e5]),
-``_prepare`` :1515-1545 (ignore2D / ignore3D flags), COCO matching per (image, category, range) and ``accumulate``
-:1547-1688 (101 recall points, mergesort on scores), ``summarize`` :2072-2224 (AP, AP15 / AP25 / AP50, near / medium /
-far). The 3D IoU is ``box3d_overlap`` (:109-169) on the HIP kernel ``ovm_box3d_iou``.
+``_prepare`` :1515-1545 (ignore2D / ignore3D flags), COCO matching per (image, category, range), ``accumulate``
+:1547-1688 (101 recall points, stable sort on scores), ``summarize`` :2072-2224 (AP, AP15 / AP25 / AP50, near / medium /
+far), ``Omni3DevalWithNHD`` :2293-2484 (disentangled NHD of IoU-matched pairs, ``nhd.py``). The 3D IoU is
+``box3d_overlap`` (:109-169) on the HIP kernel ``ovm_box3d_iou``. Ground-truth construction (filter settings, the ignore
+rule, dataset <-> contiguous category ids) is ``omni3d_gt.py``.
 
 The reference FORK lost its ``computeIoU`` override, so its "3D" AP is really computed with pycocotools' 2D IoU
 (SURVEY.md 0.5); ``fork_compat_2d_iou=True`` reproduces that behaviour, the default is upstream's.
-pycocotools is not a dependency: the matching / accumulation below is the published COCOeval algorithm.
+pycocotools is not a dependency (and not importable here, so AP values are pinned by cases with a known answer and by
+a by-definition restatement in tests/test_eval.py, not by running the reference's evaluator: "parity unpinned" for
+real-data AP).
 """
 from __future__ import annotations
 
@@ -20,6 +24,7 @@ import numpy as np
 import torch
 
 from .. import lib as _lib
+from . import nhd as _nhd
 
 
 def box3d_overlap(boxes_dt: torch.Tensor, boxes_gt: torch.Tensor, eps_coplanar: float = 1e-4, eps_nonzero: float = 1e-8) -> torch.Tensor:
@@ -75,17 +80,33 @@ class Omni3DParams:
         self.proximity_thresh = 0.3
 
 
+class _Cell:
+    """One (image, category) cell: detections in descending score order (stable), cut to the largest maxDets; ground truth
+    in file order; ``iou`` [D,G] between them."""
+    __slots__ = ("dt", "gt", "iou", "score", "dt_rng", "gt_rng", "gt_flag", "gt_crowd")
+
+
 class Omni3Deval:
     """COCO-style AP over Omni3D annotations. ``gts`` / ``dts`` are lists of dicts:
     gt: image_id, category_id, bbox [x,y,w,h], bbox3D [8][3], depth, optional area, ignore2D, ignore3D, iscrowd
-    dt: image_id, category_id, bbox, score, and for 3D bbox3D + depth (the records of ``instances_to_coco_json``)."""
+    dt: image_id, category_id, bbox, score, and for 3D bbox3D + depth (the records of ``instances_to_coco_json``).
+    ``img_ids`` / ``cat_ids``: the evaluated images and categories (the reference takes them from the ground-truth dataset,
+    :1489-1491); by default every id that occurs. In 3D mode, pairs of a detection and its best-IoU ground truth with
+    IoU >= ``nhd_iou_threshold`` also get the disentangled NHD (``Omni3DevalWithNHD`` :2293-2484) when both carry
+    centre / dimensions / rotation.
+
+    The evaluation is the published COCOeval procedure (greedy matching per IoU threshold in score order, ignore rules,
+    101-point interpolated precision); it is organised here as array operations over the thresholds rather than the
+    per-threshold loops of pycocotools, and ``tests/test_eval.py`` holds it against a by-definition restatement."""
 
     def __init__(self, gts: Sequence[Dict], dts: Sequence[Dict], mode: str = "3D", device: Optional[torch.device] = None,
-                 fork_compat_2d_iou: bool = False):
+                 fork_compat_2d_iou: bool = False, img_ids: Optional[Sequence] = None, cat_ids: Optional[Sequence] = None,
+                 nhd_iou_threshold: float = 0.5):
         self.mode = mode
         self.params = Omni3DParams(mode)
         self.device = device
         self.fork_compat_2d_iou = fork_compat_2d_iou
+        self.nhd_iou_threshold = nhd_iou_threshold
         self._gts_all, self._dts_all = [dict(g) for g in gts], [dict(d) for d in dts]
         for i, g in enumerate(self._gts_all):
             g.setdefault("id", i + 1)
@@ -96,139 +117,189 @@ class Omni3Deval:
             d.setdefault("id", i + 1)
             if "area" not in d:
                 d["area"] = float(d["bbox"][2] * d["bbox"][3])
-        self.params.imgIds = sorted({g["image_id"] for g in self._gts_all} | {d["image_id"] for d in self._dts_all})
-        self.params.catIds = sorted({g["category_id"] for g in self._gts_all} | {d["category_id"] for d in self._dts_all})
-        self.evalImgs, self.eval, self.ious = [], {}, {}
+        self.params.imgIds = sorted(img_ids) if img_ids is not None else \
+            sorted({g["image_id"] for g in self._gts_all} | {d["image_id"] for d in self._dts_all})
+        self.params.catIds = sorted(cat_ids) if cat_ids is not None else \
+            sorted({g["category_id"] for g in self._gts_all} | {d["category_id"] for d in self._dts_all})
+        self.cells: Dict = {}
+        self.per_cell: Dict = {}
+        self.eval: Dict = {}
+        self.nhd_pairs: List[Dict] = []
 
-    # ---- reference _prepare :1515-1545 -------------------------------------------------------------------------------
-    def _prepare(self):
-        flag = "ignore2D" if self.mode == "2D" else "ignore3D"
-        self._gts, self._dts = defaultdict(list), defaultdict(list)
-        for g in self._gts_all:
-            g[flag] = g[flag] if flag in g else 0
-            self._gts[g["image_id"], g["category_id"]].append(g)
-        for d in self._dts_all:
-            self._dts[d["image_id"], d["category_id"]].append(d)
+    # ---- cells and their IoU ------------------------------------------------------------------------------------------
+    def _iou_2d(self, dt, gt):
+        return iou2d_xywh(np.array([d["bbox"] for d in dt]), np.array([g["bbox"] for g in gt]))
 
-    def _range_value(self, ann):
-        return ann["area"] if self.mode == "2D" else ann["depth"]
-
-    def computeIoU(self, imgId, catId):
-        gt, dt = self._gts[imgId, catId], self._dts[imgId, catId]
-        if len(gt) == 0 or len(dt) == 0:
-            return []
-        inds = np.argsort([-d["score"] for d in dt], kind="mergesort")
-        dt = [dt[i] for i in inds]
-        if len(dt) > self.params.maxDets[-1]:
-            dt = dt[0:self.params.maxDets[-1]]
-        if self.mode == "2D" or self.fork_compat_2d_iou:
-            return iou2d_xywh(np.array([d["bbox"] for d in dt]), np.array([g["bbox"] for g in gt]))
-        dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
-        bd = torch.tensor(np.asarray([d["bbox3D"] for d in dt], np.float32), device=dev)
-        bg = torch.tensor(np.asarray([g["bbox3D"] for g in gt], np.float32), device=dev)
-        return box3d_overlap(bd, bg).cpu().numpy().astype(np.float64)
-
-    # ---- COCOeval.evaluateImg with the Omni3D ignore / range rules --------------------------------------------------------
-    def evaluateImg(self, imgId, catId, aRng, maxDet):
+    def _build_cells(self):
         p = self.params
-        gt, dt = self._gts[imgId, catId], self._dts[imgId, catId]
-        if len(gt) == 0 and len(dt) == 0:
-            return None
-        flag = "ignore2D" if self.mode == "2D" else "ignore3D"
-        for g in gt:
-            v = self._range_value(g)
-            g["_ignore"] = 1 if (g[flag] or v < aRng[0] or v > aRng[1]) else 0
-        gtind = np.argsort([g["_ignore"] for g in gt], kind="mergesort")
-        gt = [gt[i] for i in gtind]
-        dtind = np.argsort([-d["score"] for d in dt], kind="mergesort")
-        dt = [dt[i] for i in dtind[0:maxDet]]
-        iscrowd = [int(o["iscrowd"]) for o in gt]
-        ious = self.ious[imgId, catId][:, gtind] if len(self.ious[imgId, catId]) > 0 else self.ious[imgId, catId]
-        T, G, D = len(p.iouThrs), len(gt), len(dt)
-        gtm, dtm = np.zeros((T, G)), np.zeros((T, D))
-        gtIg = np.array([g["_ignore"] for g in gt])
-        dtIg = np.zeros((T, D))
-        if len(ious) != 0:
-            for tind, t in enumerate(p.iouThrs):
-                for dind, d in enumerate(dt):
-                    iou = min([t, 1 - 1e-10])
-                    m = -1
-                    for gind, g in enumerate(gt):
-                        if gtm[tind, gind] > 0 and not iscrowd[gind]:
-                            continue
-                        if m > -1 and gtIg[m] == 0 and gtIg[gind] == 1:
-                            break
-                        if ious[dind, gind] < iou:
-                            continue
-                        iou = ious[dind, gind]
-                        m = gind
-                    if m == -1:
-                        continue
-                    dtIg[tind, dind] = gtIg[m]
-                    dtm[tind, dind] = gt[m]["id"]
-                    gtm[tind, m] = d["id"]
-        a = np.array([self._range_value(d) < aRng[0] or self._range_value(d) > aRng[1] for d in dt]).reshape((1, len(dt)))
-        dtIg = np.logical_or(dtIg, np.logical_and(dtm == 0, np.repeat(a, T, 0)))
-        return {"image_id": imgId, "category_id": catId, "aRng": aRng, "maxDet": maxDet, "dtIds": [d["id"] for d in dt],
-                "gtIds": [g["id"] for g in gt], "dtMatches": dtm, "gtMatches": gtm, "dtScores": [d["score"] for d in dt],
-                "gtIgnore": gtIg, "dtIgnore": dtIg}
+        flag = "ignore2D" if self.mode == "2D" else "ignore3D"                  # _prepare :1515-1545
+        rng_key = "area" if self.mode == "2D" else "depth"
+        imgs, cats = set(p.imgIds), set(p.catIds)
+        by_gt, by_dt = defaultdict(list), defaultdict(list)
+        for g in self._gts_all:
+            if g["image_id"] in imgs and g["category_id"] in cats:
+                by_gt[g["image_id"], g["category_id"]].append(g)
+        for d in self._dts_all:
+            if d["image_id"] in imgs and d["category_id"] in cats:
+                by_dt[d["image_id"], d["category_id"]].append(d)
+        top = p.maxDets[-1]
+        self.cells = {}
+        for key in set(by_gt) | set(by_dt):
+            c = _Cell()
+            dt = by_dt.get(key, [])
+            order = np.argsort(-np.array([d["score"] for d in dt], dtype=np.float64), kind="mergesort")[:top]
+            c.dt = [dt[i] for i in order]
+            c.gt = by_gt.get(key, [])
+            c.score = np.array([d["score"] for d in c.dt], dtype=np.float64)
+            c.dt_rng = np.array([d[rng_key] for d in c.dt], dtype=np.float64)
+            c.gt_rng = np.array([g[rng_key] for g in c.gt], dtype=np.float64)
+            c.gt_flag = np.array([bool(g.get(flag, 0)) for g in c.gt], dtype=bool)
+            c.gt_crowd = np.array([bool(g["iscrowd"]) for g in c.gt], dtype=bool)
+            c.iou = None
+            self.cells[key] = c
+        true_3d = self.mode == "3D" and not self.fork_compat_2d_iou
+        if not true_3d:
+            for c in self.cells.values():
+                c.iou = self._iou_2d(c.dt, c.gt) if c.dt and c.gt else np.zeros((len(c.dt), len(c.gt)))
+            return
+        # true 3D IoU: one kernel call per IMAGE (all its detections x all its ground truth), sliced per category
+        dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+        per_image = defaultdict(list)
+        for (img, cat), c in self.cells.items():
+            if c.dt and c.gt:
+                per_image[img].append(c)
+            else:
+                c.iou = np.zeros((len(c.dt), len(c.gt)))
+        for img, cs in per_image.items():
+            bd = torch.tensor(np.asarray([d["bbox3D"] for c in cs for d in c.dt], np.float32), device=dev)
+            bg = torch.tensor(np.nan_to_num(np.asarray([g["bbox3D"] for c in cs for g in c.gt], np.float32), nan=0.0, posinf=0.0, neginf=0.0),
+                              device=dev)
+            full = np.nan_to_num(box3d_overlap(bd, bg).cpu().numpy().astype(np.float64))
+            r = q = 0
+            for c in cs:
+                c.iou = full[r:r + len(c.dt), q:q + len(c.gt)]
+                r, q = r + len(c.dt), q + len(c.gt)
+
+    # ---- greedy matching of one cell for one range, all IoU thresholds at once ----------------------------------------------
+    @staticmethod
+    def _match(iou: np.ndarray, gt_ign: np.ndarray, gt_crowd: np.ndarray, thrs: np.ndarray):
+        """``iou`` [D,G] with the ground truth already ordered not-ignored first. Per threshold, detections pick in score
+        order the free ground truth of highest IoU >= threshold - a later one on equal IoU - among the not-ignored ones, and
+        only when none qualifies among the ignored ones; crowd ground truth never fills up. Returns the picked index [T,D]
+        (-1: none) and whether the pick is an ignored ground truth [T,D]."""
+        T, (D, G) = len(thrs), iou.shape
+        pick = -np.ones((T, D), dtype=np.int64)
+        if D == 0 or G == 0:
+            return pick, np.zeros((T, D), dtype=bool)
+        floor = np.minimum(thrs, 1 - 1e-10)
+        taken = np.zeros((T, G), dtype=bool)
+        rows = np.arange(T)
+        keep_open = gt_crowd[None, :]
+        groups = (~gt_ign[None, :], gt_ign[None, :])
+        for d in range(D):
+            free = ~taken | keep_open
+            chosen = -np.ones(T, dtype=np.int64)
+            for grp in groups:
+                v = np.where(free & grp, iou[d][None, :], -1.0)
+                last_best = G - 1 - np.argmax(v[:, ::-1], axis=1)
+                ok = (v[rows, last_best] >= floor) & (chosen < 0)
+                chosen = np.where(ok, last_best, chosen)
+            hit = chosen >= 0
+            taken[rows[hit], chosen[hit]] = True
+            pick[:, d] = chosen
+        return pick, np.where(pick >= 0, gt_ign[np.clip(pick, 0, None)], False)
+
+    def _evaluate_cell(self, c: _Cell, rng):
+        lo, hi = rng
+        gt_ign = c.gt_flag | (c.gt_rng < lo) | (c.gt_rng > hi)
+        order = np.argsort(gt_ign, kind="mergesort")                           # not-ignored first, file order within
+        pick, on_ignored = self._match(c.iou[:, order] if c.iou.size else c.iou.reshape(len(c.dt), len(c.gt)), gt_ign[order],
+                                       c.gt_crowd[order], self.params.iouThrs)
+        matched = pick >= 0
+        outside = (c.dt_rng < lo) | (c.dt_rng > hi)
+        return {"score": c.score, "matched": matched, "ignored": on_ignored | (~matched & outside[None, :]),
+                "n_gt": int(np.count_nonzero(~gt_ign)), "gt_order": order, "pick": pick}
 
     def evaluate(self):
         p = self.params
-        self._prepare()
-        self.ious = {(i, c): self.computeIoU(i, c) for i in p.imgIds for c in p.catIds}
-        maxDet = p.maxDets[-1]
-        self.evalImgs = [self.evaluateImg(i, c, a, maxDet) for c in p.catIds for a in p.areaRng for i in p.imgIds]
+        self._build_cells()
+        self.per_cell = {(key, a): self._evaluate_cell(c, rng) for key, c in self.cells.items() for a, rng in enumerate(p.areaRng)}
+        if self.mode == "3D":
+            self._collect_nhd()
 
-    # ---- COCOeval.accumulate (reference :1547-1688) -----------------------------------------------------------------------
+    # ---- precision / recall tables ----------------------------------------------------------------------------------------
     def accumulate(self):
+        """precision[T,R,K,A,M], recall[T,K,A,M], scores[T,R,K,A,M] with -1 where a (category, range) has no countable ground
+        truth - the layout of COCOeval.accumulate (reference :1547-1688), which the per-category tables read."""
         p = self.params
         T, R, K, A, M = len(p.iouThrs), len(p.recThrs), len(p.catIds), len(p.areaRng), len(p.maxDets)
         precision, recall, scores = -np.ones((T, R, K, A, M)), -np.ones((T, K, A, M)), -np.ones((T, R, K, A, M))
-        I0, A0 = len(p.imgIds), len(p.areaRng)
-        for k in range(K):
-            Nk = k * A0 * I0
+        cells_of_cat = defaultdict(list)
+        for (img, cat) in self.cells:
+            cells_of_cat[cat].append(img)
+        img_rank = {img: i for i, img in enumerate(p.imgIds)}
+        tiny = np.spacing(1)
+        for k, cat in enumerate(p.catIds):
+            imgs = sorted(cells_of_cat.get(cat, ()), key=img_rank.__getitem__)     # concatenation order decides ties between images
+            if not imgs:
+                continue
             for a in range(A):
-                Na = a * I0
-                for m, maxDet in enumerate(p.maxDets):
-                    E = [self.evalImgs[Nk + Na + i] for i in range(I0)]
-                    E = [e for e in E if e is not None]
-                    if len(E) == 0:
-                        continue
-                    dtScores = np.concatenate([e["dtScores"][0:maxDet] for e in E])
-                    inds = np.argsort(-dtScores, kind="mergesort")
-                    dtScoresSorted = dtScores[inds]
-                    dtm = np.concatenate([e["dtMatches"][:, 0:maxDet] for e in E], axis=1)[:, inds]
-                    dtIg = np.concatenate([e["dtIgnore"][:, 0:maxDet] for e in E], axis=1)[:, inds]
-                    gtIg = np.concatenate([e["gtIgnore"] for e in E])
-                    npig = np.count_nonzero(gtIg == 0)
-                    if npig == 0:
-                        continue
-                    tps = np.logical_and(dtm, np.logical_not(dtIg))
-                    fps = np.logical_and(np.logical_not(dtm), np.logical_not(dtIg))
-                    tp_sum = np.cumsum(tps, axis=1).astype(dtype=float)
-                    fp_sum = np.cumsum(fps, axis=1).astype(dtype=float)
-                    for t, (tp, fp) in enumerate(zip(tp_sum, fp_sum)):
-                        tp, fp = np.array(tp), np.array(fp)
-                        nd = len(tp)
-                        rc = tp / npig
-                        pr = tp / (fp + tp + np.spacing(1))
-                        q, ss = np.zeros((R,)), np.zeros((R,))
-                        recall[t, k, a, m] = rc[-1] if nd else 0
-                        pr, q = pr.tolist(), q.tolist()
-                        for i in range(nd - 1, 0, -1):
-                            if pr[i] > pr[i - 1]:
-                                pr[i - 1] = pr[i]
-                        inds_r = np.searchsorted(rc, p.recThrs, side="left")
-                        try:
-                            for ri, pi in enumerate(inds_r):
-                                q[ri] = pr[pi]
-                                ss[ri] = dtScoresSorted[pi]
-                        except IndexError:
-                            pass
-                        precision[t, :, k, a, m] = np.array(q)
-                        scores[t, :, k, a, m] = np.array(ss)
+                res = [self.per_cell[(img, cat), a] for img in imgs]
+                n_gt = sum(r["n_gt"] for r in res)
+                if n_gt == 0:
+                    continue
+                for m, cap in enumerate(p.maxDets):
+                    sc = np.concatenate([r["score"][:cap] for r in res])
+                    order = np.argsort(-sc, kind="mergesort")
+                    sc = sc[order]
+                    hit = np.concatenate([r["matched"][:, :cap] for r in res], axis=1)[:, order]
+                    ign = np.concatenate([r["ignored"][:, :cap] for r in res], axis=1)[:, order]
+                    tp = np.cumsum(hit & ~ign, axis=1, dtype=np.float64)
+                    fp = np.cumsum(~hit & ~ign, axis=1, dtype=np.float64)
+                    nd = sc.shape[0]
+                    recall[:, k, a, m] = tp[:, -1] / n_gt if nd else 0.0
+                    prec_tab, score_tab = np.zeros((T, R)), np.zeros((T, R))
+                    if nd:
+                        rc = tp / n_gt
+                        pr = tp / (fp + tp + tiny)
+                        envelope = np.maximum.accumulate(pr[:, ::-1], axis=1)[:, ::-1]      # best precision at this recall or beyond
+                        for t in range(T):
+                            at = np.searchsorted(rc[t], p.recThrs, side="left")
+                            reach = at < nd
+                            prec_tab[t, reach] = envelope[t, at[reach]]
+                            score_tab[t, reach] = sc[at[reach]]
+                    precision[:, :, k, a, m] = prec_tab
+                    scores[:, :, k, a, m] = score_tab
         self.eval = {"params": p, "counts": [T, R, K, A, M], "precision": precision, "recall": recall, "scores": scores}
+        if self.mode == "3D":
+            acc = {key: [pair[key] for pair in self.nhd_pairs] for key in ("overall",) + _nhd.COMPONENTS}
+            self.eval["nhd_accumulators"] = acc
+            self.eval["average_nhd"] = {key: (float(np.mean(v)) if v else float("nan")) for key, v in acc.items()}
+
+    # ---- disentangled NHD over IoU-matched pairs (reference :2342-2484) -----------------------------------------------------
+    def _collect_nhd(self):
+        """A detection is paired with its highest-IoU ground truth of the cell (the first one on ties, IoU > 0) when that IoU
+        reaches ``nhd_iou_threshold``. The reference evaluates the same pairs once per depth range and averages over all of
+        them, which leaves the mean where it is; here each pair is scored once. (Its IoU lookup reads the matrix in
+        un-reordered ground-truth order while walking the reordered list, :2363-2392; the pairing here follows the intent.)"""
+        need_dt, need_gt = ("center_cam", "dimensions", "pose", "depth"), ("center_cam", "dimensions", "R_cam", "depth")
+        self.nhd_pairs = []
+        for key in sorted(self.cells, key=lambda k: (str(k[1]), str(k[0]))):
+            c = self.cells[key]
+            if not c.dt or not c.gt or c.iou.size == 0:
+                continue
+            best = np.argmax(c.iou, axis=1)
+            for di, gi in enumerate(best):
+                v = c.iou[di, gi]
+                d, g = c.dt[di], c.gt[gi]
+                if not (v > 0 and v >= self.nhd_iou_threshold) or any(f not in d for f in need_dt) or any(f not in g for f in need_gt):
+                    continue
+                pred = {"xy": d["center_cam"][:2], "z": d["depth"], "dimensions": d["dimensions"], "pose": d["pose"]}
+                true = {"xy": g["center_cam"][:2], "z": g["depth"], "dimensions": g["dimensions"], "pose": g["R_cam"]}
+                try:
+                    self.nhd_pairs.append(_nhd.disentangled_nhd(pred, true))
+                except Exception:                                               # a degenerate box: the reference logs and moves on (:2424-2426)
+                    continue
 
     # ---- summarize (reference :2072-2224) ----------------------------------------------------------------------------------
     def _summarize(self, ap=1, iouThr=None, areaRng="all", maxDets=100):
@@ -251,52 +322,64 @@ class Omni3Deval:
                     ("APm", None, "medium"), ("APf", None, "far")]
         out = {k: self._summarize(1, thr, rng) * 100 for k, thr, rng in keys}
         out["AR100"] = self._summarize(0, None, "all", 100) * 100
+        if self.mode == "3D" and "average_nhd" in self.eval:
+            for comp, v in self.eval["average_nhd"].items():
+                out["NHD" if comp == "overall" else f"NHD-{comp}"] = v
         self.stats = out
         return out
 
-    def per_category_ap(self, class_names: Optional[Sequence[str]] = None) -> Dict:
-        """mean precision per category at area 'all', maxDets 100 (reference _derive_omni_results :1729-1819)."""
+    def per_category_ap(self, class_names=None) -> Dict:
+        """mean precision per category at area 'all', maxDets 100 (reference _derive_omni_results :1729-1819). ``class_names``:
+        a dict id -> name, or a sequence indexed by the id."""
         prec = self.eval["precision"]
         out = {}
         for k, cid in enumerate(self.params.catIds):
             s = prec[:, :, k, 0, -1]
             s = s[s > -1]
-            name = class_names[cid] if class_names is not None and cid < len(class_names) else cid
+            if isinstance(class_names, dict):
+                name = class_names.get(cid, cid)
+            else:
+                name = class_names[cid] if class_names is not None and cid < len(class_names) else cid
             out[name] = float(np.mean(s) * 100) if s.size else float("nan")
         return out
 
 
-def evaluate_omni3d(gts: Sequence[Dict], dts: Sequence[Dict], device=None, only_2d: bool = False, fork_compat_2d_iou: bool = False) -> Dict:
-    """AP2D and AP3D dictionaries for one dataset (reference _evaluate_predictions_on_omni :1255-1391 without the file plumbing)."""
+def evaluate_omni3d(gts, dts: Sequence[Dict], device=None, only_2d: bool = False, fork_compat_2d_iou: bool = False,
+                    category_map=None, passthrough_dataset_ids: bool = False) -> Dict:
+    """AP2D and AP3D dictionaries for one dataset (reference _evaluate_predictions_on_omni :1255-1391 without the file plumbing).
+
+    ``gts``: an ``Omni3DGroundTruth`` (images and categories evaluated = the dataset's, as the reference; detections on unknown
+    images or categories are dropped :1319-1334) or a plain list of ground-truth dicts. ``category_map`` (``CategoryMap``): the
+    detections carry the model's contiguous class index and are un-mapped to dataset ids first (:1029-1093)."""
+    from .omni3d_gt import Omni3DGroundTruth, ground_truth_records
+    img_ids = cat_ids = names = None
+    if isinstance(gts, Omni3DGroundTruth):
+        img_ids, cat_ids = list(gts.image_ids), list(gts.category_ids)
+        names = dict(zip(gts.category_ids, gts.category_names))
+        gts = ground_truth_records(gts)
+    if category_map is not None:
+        dts = category_map.detections_to_dataset_ids(dts, passthrough_dataset_ids)
+    if img_ids is not None:
+        known_i, known_c = set(img_ids), set(cat_ids)
+        dts = [d for d in dts if d["image_id"] in known_i and d["category_id"] in known_c]
     res = {}
-    e2 = Omni3Deval(gts, dts, "2D")
+    e2 = Omni3Deval(gts, dts, "2D", img_ids=img_ids, cat_ids=cat_ids)
     e2.evaluate(); e2.accumulate()
     res["bbox_2D"] = e2.summarize()
+    if names is not None:
+        res["bbox_2D_per_category"] = e2.per_category_ap(names)
     if not only_2d:
         d3 = [d for d in dts if "bbox3D" in d]
-        e3 = Omni3Deval(gts, d3, "3D", device=device, fork_compat_2d_iou=fork_compat_2d_iou)
+        e3 = Omni3Deval(gts, d3, "3D", device=device, fork_compat_2d_iou=fork_compat_2d_iou, img_ids=img_ids, cat_ids=cat_ids)
         e3.evaluate(); e3.accumulate()
         res["bbox_3D"] = e3.summarize()
+        if names is not None:
+            res["bbox_3D_per_category"] = e3.per_category_ap(names)
     return res
 
 
-def omni3d_json_to_gt(dataset_json: Dict) -> List[Dict]:
-    """Ground-truth records from an Omni3D annotation file (the fields the reference's loader keeps, cubercnn/data/datasets.py:
-    `bbox2D_proj` / `bbox2D_tight` / `bbox2D_trunc` xyxy, `bbox3D_cam` 8x3, `center_cam`, `behind_camera`). A simplification of the
-    reference's `is_ignore` filter settings: an annotation is ignored in 3D when it is behind the camera or has no valid 3D box,
-    in 2D when it has no valid 2D box."""
-    out = []
-    for a in dataset_json.get("annotations", []):
-        box = None
-        for k in ("bbox2D_proj", "bbox2D_tight", "bbox2D_trunc", "bbox"):
-            b = a.get(k)
-            if b is not None and len(b) == 4 and b[0] != -1:
-                box = [float(b[0]), float(b[1]), float(b[2] - b[0]), float(b[3] - b[1])] if k != "bbox" else [float(v) for v in b]
-                break
-        c3 = a.get("bbox3D_cam")
-        valid3 = c3 is not None and np.asarray(c3).shape == (8, 3) and not a.get("behind_camera", False)
-        depth = float(a["center_cam"][2]) if a.get("center_cam") is not None else (float(np.mean(np.asarray(c3)[:, 2])) if valid3 else 0.0)
-        out.append({"image_id": a["image_id"], "category_id": a["category_id"], "bbox": box if box is not None else [0.0, 0.0, 0.0, 0.0],
-                    "bbox3D": c3 if valid3 else np.zeros((8, 3)).tolist(), "depth": depth, "ignore2D": int(box is None),
-                    "ignore3D": int(not valid3), "iscrowd": 0})
-    return out
+def omni3d_json_to_gt(dataset_json: Dict, filter_settings: Optional[Dict] = None) -> List[Dict]:
+    """Ground-truth records of an Omni3D annotation dict under the reference's filter settings (defaults: datasets.py:55-66);
+    see ``omni3d_gt.Omni3DGroundTruth`` for the rules."""
+    from .omni3d_gt import Omni3DGroundTruth, filter_settings_from_cfg, ground_truth_records
+    return ground_truth_records(Omni3DGroundTruth(dataset_json, filter_settings if filter_settings is not None else filter_settings_from_cfg(None)))

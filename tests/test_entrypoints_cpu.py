@@ -201,3 +201,27 @@ def test_oracle2d_file_defaults_resolve(tmp_path):
     (tmp_path / "gdino_objectron_base_oracle_2d.json").write_text("[]")
     assert tn.oracle2d_file(cfg, "base", "Objectron_test", str(tmp_path)).endswith("gdino_objectron_base_oracle_2d.json")
     assert tn.oracle2d_file(cfg, "base", "NoSuch_test", str(tmp_path)) is None
+
+
+def test_category_map_of_the_eval_entry_point(tmp_path):
+    """tools/train_net.py picks the class-index <-> dataset-id map from the annotation file's category table (for Objectron
+    the numbering 11, 14..21 -> 0..8, i.e. what the reference hard-codes as configs/category_objectron.json), or from a
+    category_meta.json-style file."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from tools.train_net import category_map_for, make_cfg
+    from ovmono3d_amd.evaluation import Omni3DGroundTruth, eval_filter_settings
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = make_cfg(os.path.join(root, "configs", "OVMono3D_dinov2_SFP.yaml"), [])
+    fs = eval_filter_settings(cfg, "base")
+    assert fs["min_height_thres"] == 0.0625 and fs["max_depth"] == 1e8 and fs["trunc_2D_boxes"] is True
+    assert fs["truncation_thres"] == cfg.TEST.TRUNCATION_THRES and fs["visibility_thres"] == cfg.TEST.VISIBILITY_THRES
+    assert fs["category_names"] == list(cfg.DATASETS.CATEGORY_NAMES_BASE) and fs["ignore_names"] == ["dontcare", "ignore", "void"]
+    names = ("bicycle", "books", "bottle", "camera", "cereal box", "chair", "cup", "laptop", "shoes", "sofa")
+    cats = [{"id": i, "name": n} for i, n in zip((11, 14, 15, 16, 17, 18, 19, 20, 21, 40), names)]
+    gt = Omni3DGroundTruth({"info": {}, "images": [{"id": 1, "height": 100}], "annotations": [], "categories": cats}, fs)
+    cm = category_map_for(cfg, "base", gt)
+    assert cm.contiguous_to_dataset_id == dict(enumerate((11, 14, 15, 16, 17, 18, 19, 20, 21))) and cm.thing_classes == list(names[:9])
+    meta = tmp_path / "category_meta.json"
+    meta.write_text(json.dumps({"thing_classes": ["chair", "sofa"], "thing_dataset_id_to_contiguous_id": {"18": 0, "40": 1}}))
+    assert category_map_for(cfg, "base", gt, str(meta)).contiguous_to_dataset_id == {0: 18, 1: 40}

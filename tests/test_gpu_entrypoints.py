@@ -84,11 +84,18 @@ def test_eval_only_entry_point(device, tmp_path):
     images = [{"id": 100 + i, "file_path": f"imgs/{n}.png", "width": 160, "height": 120 + 20 * i, "dataset_id": 0,
                "K": [[300.0, 0, 80], [0, 300.0, 60 + 10 * i], [0, 0, 1]]} for i, n in enumerate(names)]
     c3 = [[x, y, z] for z in (4.5, 5.5) for (x, y) in ((-0.5, -0.5), (0.5, -0.5), (0.5, 0.5), (-0.5, 0.5))]
-    anns = [{"id": 1, "image_id": 100, "category_id": 3, "bbox2D_proj": [20, 20, 80, 70], "bbox3D_cam": c3, "center_cam": [0, 0, 5.0],
-             "behind_camera": False},
-            {"id": 2, "image_id": 101, "category_id": 7, "bbox2D_proj": [-1, -1, -1, -1], "bbox2D_tight": [30, 30, 90, 90], "bbox3D_cam": c3,
-             "center_cam": [0, 0, 5.0], "behind_camera": True}]
-    (root / "Omni3D" / "Objectron_test.json").write_text(json.dumps({"images": images, "annotations": anns, "categories": []}))
+    full = {"valid3D": True, "dimensions": [1.0, 1.0, 1.0], "lidar_pts": -1, "segmentation_pts": -1, "depth_error": -1, "truncation": 0.0,
+            "visibility": 1.0, "bbox2D_trunc": [-1, -1, -1, -1], "bbox2D_tight": [-1, -1, -1, -1], "R_cam": np.eye(3).tolist(),
+            "bbox3D_cam": c3, "center_cam": [0, 0, 5.0], "behind_camera": False}
+    anns = [dict(full, id=1, image_id=100, category_id=18, category_name="chair", bbox2D_proj=[20, 20, 80, 70]),
+            dict(full, id=2, image_id=101, category_id=19, category_name="cup", bbox2D_proj=[-1, -1, -1, -1], bbox2D_tight=[30, 30, 90, 90],
+                 behind_camera=True),
+            dict(full, id=3, image_id=102, category_id=40, category_name="sofa", bbox2D_proj=[20, 20, 80, 70])]     # not a base category
+    # the Objectron numbering (ids 11, 14..21) plus one category that is not evaluated: dataset ids differ from class indices
+    cats = [{"id": i, "name": n} for i, n in zip((11, 14, 15, 16, 17, 18, 19, 20, 21, 40),
+                                                 ("bicycle", "books", "bottle", "camera", "cereal box", "chair", "cup", "laptop", "shoes", "sofa"))]
+    (root / "Omni3D" / "Objectron_test.json").write_text(json.dumps({"info": {"name": "Objectron"}, "images": images, "annotations": anns,
+                                                                     "categories": cats}))
     out = tmp_path / "out"
     cmd = [sys.executable, os.path.join(ROOT, "tools", "train_net.py"), "--eval-only", "--config-file",
            os.path.join(ROOT, "configs", "OVMono3D_dinov2_SFP.yaml"), "--datasets-root", str(root / "Omni3D"), "--image-root", str(root),
@@ -101,6 +108,10 @@ def test_eval_only_entry_point(device, tmp_path):
     ap = json.loads((out / "inference" / "iter_final" / "Objectron_test" / "omni_ap.json").read_text())      # AP evaluator ran on the ground truth
     assert {"AP", "AP15", "AP25", "AP50", "APn", "APm", "APf"} <= set(ap["bbox_3D"]) and {"AP", "AP50", "AP75"} <= set(ap["bbox_2D"])
     assert {r_["image_id"] for r_ in res} <= {100, 101, 102}
+    assert "NHD" in ap["bbox_3D"] and set(ap["bbox_3D_per_category"]) == {"bicycle", "books", "bottle", "camera", "cereal box", "chair", "cup",
+                                                                            "laptop", "shoes"}
+    meta = json.loads((out / "inference" / "iter_final" / "Objectron_test" / "category_meta.json").read_text())
+    assert meta["thing_dataset_id_to_contiguous_id"] == {"11": 0, "14": 1, "15": 2, "16": 3, "17": 4, "18": 5, "19": 6, "20": 7, "21": 8}
 
 
 def test_oracle2d_producer_roundtrip(device, tmp_path):
@@ -120,7 +131,7 @@ def test_oracle2d_producer_roundtrip(device, tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     data = json.loads(out.read_text())
-    assert [d["image_id"] for d in data] == [7, 8] and all(i["category_id"] in (3, 9) for d in data for i in d["instances"])
+    assert [d["image_id"] for d in data] == [7, 8] and all(i["category_id"] in (0, 1) for d in data for i in d["instances"])
     assert sum(len(d["instances"]) for d in data) > 0
     dicts = load_omni3d_json(str(ds), str(root))
     merge_oracle2d_to_detection_dicts(dicts, str(out))

@@ -11,7 +11,10 @@ cubercnn/config/config.py:69-76, README.md:70-74): a list aligned with the datas
       MODEL.AMD.GDINO_WEIGHTS checkpoints/groundingdino_swinb_cogcoor.pth MODEL.AMD.BERT_VOCAB bert-base-uncased/vocab.txt
 
 Categories prompted per image: ``--categories a,b,c`` (one list for the whole file) or, by default, the ``categories`` of the
-annotation file in id order; ``category_id`` in the output is the id of the matched category.
+annotation file in id order. ``category_id`` in the output is what the cube head passes on as ``pred_classes``
+(reference roi_heads_gdino.py:108-121), i.e. the model's CONTIGUOUS class index: the rank of the matched category among the
+prompted ones ordered by dataset id (datasets.py:294-320) - the id space the evaluator un-maps (tools/train_net.py here,
+omni3d_evaluation.py:1029-1093 there). ``--dataset-ids`` writes the annotation file's own category ids instead.
 """
 import argparse
 import json
@@ -49,6 +52,7 @@ def main():
     ap.add_argument("--image-root", default="datasets")
     ap.add_argument("--output", required=True)
     ap.add_argument("--categories", default="", help="comma separated prompt list (default: the file's categories)")
+    ap.add_argument("--dataset-ids", action="store_true", help="write the annotation file's category ids, not class indices")
     ap.add_argument("--box-threshold", type=float, default=0.001)
     ap.add_argument("--nms-threshold", type=float, default=0.5)
     ap.add_argument("opts", nargs=argparse.REMAINDER)
@@ -63,7 +67,8 @@ def main():
         ids = list(range(len(names)))
     else:
         cats = sorted(meta.get("categories", []), key=lambda c: c["id"])
-        names, ids = [c["name"] for c in cats], [c["id"] for c in cats]
+        names = [c["name"] for c in cats]
+        ids = [c["id"] for c in cats] if args.dataset_ids else list(range(len(cats)))
     if not names:
         raise SystemExit("no categories to prompt: pass --categories or use an annotation file with a categories section")
     caption, cap_list = build_caption(names)

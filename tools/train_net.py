@@ -6,8 +6,10 @@ dataset (the reference's ``eval_helper.save_predictions``, tools/train_net.py:10
 
 Launch: ``python tools/train_net.py --eval-only --config-file configs/OVMono3D_dinov2_SFP.yaml --num-gpus N
 MODEL.WEIGHTS <ckpt> OUTPUT_DIR <dir>`` (N > 1 re-launches itself under torch.distributed.run, one rank
-per GPU over RCCL). Rank 0 then runs the Omni3D AP evaluator (``evaluation/omni3d_eval.py``: AP2D / AP3D with true 3D IoU,
-written to ``omni_ap.json``). Training (``do_train``) is out of scope.
+per GPU over RCCL). Rank 0 then runs the Omni3D AP evaluator under the reference's evaluation rules (``evaluation/omni3d_gt.py``:
+filter settings of its do_test, the ignore rule, ground truth in dataset category ids, detections un-mapped from the model's
+class index; ``evaluation/omni3d_eval.py``: AP2D / AP3D with true 3D IoU and the disentangled NHD), written to ``omni_ap.json``
+next to the ``category_meta.json`` that was applied. Training (``do_train``) is out of scope.
 
 Deviations from the fork, both restoring upstream intent: oracle-2D boxes are
 forwarded to the model when TEST.ORACLE2D is set and the oracle file exists, and TEST.CAT_MODE selects the mode.
@@ -27,7 +29,8 @@ from ovmono3d_amd.checkpoint import DetectionCheckpointer  # noqa: E402
 from ovmono3d_amd.data import (DatasetMapper3D, build_detection_test_loader, load_omni3d_json,  # noqa: E402
                                merge_oracle2d_to_detection_dicts)
 from ovmono3d_amd.defaults import make_cfg  # noqa: E402
-from ovmono3d_amd.evaluation import Omni3DEvaluator, evaluate_omni3d, inference_on_dataset, omni3d_json_to_gt  # noqa: E402
+from ovmono3d_amd.evaluation import (CategoryMap, Omni3DEvaluator, Omni3DGroundTruth, eval_filter_settings,  # noqa: E402
+                                     evaluate_omni3d, inference_on_dataset)
 from ovmono3d_amd.evaluation.distributed import get_rank, get_world_size  # noqa: E402
 from ovmono3d_amd.modeling import build_model  # noqa: E402
 
@@ -48,7 +51,7 @@ def oracle2d_file(cfg, mode, name, datasets_root):
     return None
 
 
-def do_test(cfg, model, mode="base", datasets_root="datasets/Omni3D", image_root="datasets", depth_dir=None):
+def do_test(cfg, model, mode="base", datasets_root="datasets/Omni3D", image_root="datasets", depth_dir=None, category_meta=None):
     if mode == "novel":
         names = cfg.DATASETS.TEST_NOVEL
     elif mode == "base":
@@ -72,15 +75,31 @@ def do_test(cfg, model, mode="base", datasets_root="datasets/Omni3D", image_root
             with open(os.path.join(out_dir, name, "omni_instances_results.json"), "w") as f:
                 json.dump([inst for r in results for inst in r["instances"]], f)
             logger.info("%s: %d images, %d detections", name, len(results), sum(len(r["instances"]) for r in results))
-            # AP2D / AP3D (true 3D IoU on the device) when the annotation file carries ground truth
-            with open(os.path.join(datasets_root, name + ".json")) as f:
-                gts = omni3d_json_to_gt(json.load(f))
-            if gts:
-                ap = evaluate_omni3d(gts, [inst for r in results for inst in r["instances"]])
+            # AP2D / AP3D (true 3D IoU on the device) under the reference's evaluation rules: the filter settings of its
+            # do_test (tools/train_net.py:59-70), ground truth in DATASET category ids, detections un-mapped from the model's
+            # contiguous class index (omni3d_evaluation.py:1029-1093)
+            gt = Omni3DGroundTruth(os.path.join(datasets_root, name + ".json"), eval_filter_settings(cfg, mode))
+            if len(gt):
+                cmap = category_map_for(cfg, mode, gt, category_meta)
+                ap = evaluate_omni3d(gt, [inst for r in results for inst in r["instances"]], category_map=cmap)
                 with open(os.path.join(out_dir, name, "omni_ap.json"), "w") as f:
                     json.dump(ap, f)
-                logger.info("%s: AP2D %.2f  AP3D %.2f  (AP3D@15 %.2f, @25 %.2f, @50 %.2f)", name, ap["bbox_2D"]["AP"], ap["bbox_3D"]["AP"],
-                            ap["bbox_3D"]["AP15"], ap["bbox_3D"]["AP25"], ap["bbox_3D"]["AP50"])
+                with open(os.path.join(out_dir, name, "category_meta.json"), "w") as f:
+                    json.dump(cmap.to_meta(), f)
+                logger.info("%s: AP2D %.2f  AP3D %.2f  (AP3D@15 %.2f, @25 %.2f, @50 %.2f)  NHD %.4f", name, ap["bbox_2D"]["AP"],
+                            ap["bbox_3D"]["AP"], ap["bbox_3D"]["AP15"], ap["bbox_3D"]["AP25"], ap["bbox_3D"]["AP50"], ap["bbox_3D"]["NHD"])
+
+
+def category_map_for(cfg, mode, gt, category_meta=None):
+    """Which contiguous class index the model's detections carry. A ``category_meta.json``-style file when given
+    (the reference hard-codes configs/category_objectron.json for *_test / *_novel datasets, omni3d_evaluation.py:1015-1020);
+    else the evaluated category names of the mode ranked by their dataset id in the annotation file's own category table
+    (the rule of datasets.py:294-320 - for Objectron_test this IS the Objectron map: ids 11,14..21 -> 0..8)."""
+    if category_meta:
+        return CategoryMap.from_meta(category_meta)
+    names = cfg.DATASETS.CATEGORY_NAMES_NOVEL if mode == "novel" else cfg.DATASETS.CATEGORY_NAMES_BASE
+    known = {c["name"] for c in gt.all_categories}
+    return CategoryMap.from_names([n for n in names if n in known], gt.all_categories)
 
 
 def main(args):
@@ -102,10 +121,10 @@ def main(args):
         set_native_comm(NativeComm.from_torch_distributed(torch.device("cuda", local_rank)))
     DetectionCheckpointer(model, save_dir=cfg.OUTPUT_DIR).resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume)
     if cfg.TEST.CAT_MODE == "all":
-        do_test(cfg, model, "novel", args.datasets_root, args.image_root, args.depth_dir)
-        do_test(cfg, model, "base", args.datasets_root, args.image_root, args.depth_dir)
+        do_test(cfg, model, "novel", args.datasets_root, args.image_root, args.depth_dir, args.category_meta)
+        do_test(cfg, model, "base", args.datasets_root, args.image_root, args.depth_dir, args.category_meta)
     else:
-        do_test(cfg, model, cfg.TEST.CAT_MODE, args.datasets_root, args.image_root, args.depth_dir)
+        do_test(cfg, model, cfg.TEST.CAT_MODE, args.datasets_root, args.image_root, args.depth_dir, args.category_meta)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
@@ -123,6 +142,8 @@ def default_argument_parser():
     p.add_argument("--datasets-root", default="datasets/Omni3D", help="(native build) folder of the Omni3D JSON files")
     p.add_argument("--image-root", default="datasets")
     p.add_argument("--depth-dir", default=None, help="(native build) folder of depth-prompt .npz files")
+    p.add_argument("--category-meta", default=None, help="(native build) category_meta.json-style file: thing_classes + "
+                   "thing_dataset_id_to_contiguous_id of the model's class index; default: derived from the annotation file")
     p.add_argument("opts", default=None, nargs=argparse.REMAINDER)
     return p
 
