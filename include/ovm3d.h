@@ -53,7 +53,7 @@ typedef struct OvmConfig {
   int32_t pooler_min_level, pooler_max_level; /* ROIPooler level clamp */
   float virtual_focal;      /* ROI_CUBE_HEAD.VIRTUAL_FOCAL */
   /* RPN + box head (reference configs/Base.yaml:45-66) */
-  float anchor_sizes[3];
+  float anchor_sizes[4];    /* one size per pyramid level (3 levels: the 4th is unused) */
   float anchor_ratios[3];
   int32_t rpn_pre_topk, rpn_post_topk;
   float rpn_nms_thresh;
@@ -62,7 +62,19 @@ typedef struct OvmConfig {
   /* build-specific */
   int32_t precision;        /* 1 = fp16 operands, one MFMA pass; 3 = split fp16 (hi+lo), three passes */
   int32_t max_batch, max_rois;
+  /* Which ViT feeds the simple feature pyramid (MODEL.BACKBONE.NAME):
+   *   OVM_TOWER_DINOV2 (0)  build_dino_backbone, reference cubercnn/modeling/backbone/dino.py:17-153: hub DINOv2, patch 14,
+   *                         LayerScale, erf-GELU, LN eps 1e-6, pos-embed bicubic with the +0.1 offset; pyramid scales (2, 1, 0.5)
+   *                         -> p2..p4 at strides 7 / 14 / 28; checkpoint keys backbone.net.vit.*
+   *   OVM_TOWER_CLIP   (1)  build_clip_backbone, reference cubercnn/modeling/backbone/clip.py:17-166: open_clip VisionTransformer
+   *                         image tower (conv1 without bias, class_embedding, ln_pre, QuickGELU, LN eps 1e-5, no ln_post / proj),
+   *                         patch 16, pos-embed resized with antialiased bicubic (:98-133); pyramid scales (4, 2, 1, 0.5)
+   *                         -> p2..p5 at strides 4 / 8 / 16 / 32; checkpoint keys backbone.net.visual.*; prompt_depth refused
+   *                         (detectron2's SimpleFeaturePyramid.forward takes no depth: SURVEY.md 0.4). */
+  int32_t tower;
 } OvmConfig;
+
+enum { OVM_TOWER_DINOV2 = 0, OVM_TOWER_CLIP = 1 };
 
 /* One host-resident fp32 tensor of a checkpoint, named with the reference state_dict key
  * (module tree printed at reference nohup.out:563-684; loaded at reference demo/demo.py:148). */
@@ -105,6 +117,9 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
 int ovm_destroy(OvmHandle* h);
 const char* ovm_last_error(const OvmHandle* h);
 const char* ovm_version(void);
+/* sizeof() of a struct of this header as the library was compiled ("OvmConfig", "OvmTensor", "OvmImage", "OvmDet3D",
+ * "OvmGdinoConfig"), -1 for an unknown name: lets a binding check its mirror of the layout before the first call. */
+int ovm_abi_sizeof(const char* struct_name);
 
 /* --- backbone: build_dino_backbone(...).forward(x, prompt_depth) -> {p2,p3,p4}
  * (reference dino.py:70-120,123-153,208-224; preprocess_image folded in, rcnn3d.py:88).
@@ -113,6 +128,12 @@ const char* ovm_version(void);
  * the features only inside the handle (ovm_cube_forward / ovm_rpn_box_forward read them there). */
 int ovm_backbone_forward(OvmHandle* h, const OvmImage* images, int32_t B, const float* prompt_depth,
                          int32_t depth_h, int32_t depth_w, float* p2, float* p3, float* p4, ovm_stream_t stream);
+
+/* The pyramid the handle holds after ovm_backbone_forward, level by level (0 = finest, "p2"): number of levels (3 or 4 by
+ * tower), and for one level its device pointer (fp32 NHWC [max_batch][side][side][fpn_channels], valid until the next forward
+ * or ovm_destroy), side and stride in pixels. The 4-level towers' p5 is read this way. */
+int ovm_backbone_num_levels(const OvmHandle* h);
+int ovm_backbone_level(const OvmHandle* h, int32_t level, const float** data, int32_t* side, float* stride);
 
 /* --- ROIHeads3D._forward_cube, eval branch (reference roi_heads.py:329-549,798-848) followed by
  * GeneralizedRCNN._postprocess (rcnn3d.py:115). Uses the features of the last ovm_backbone_forward.
@@ -166,6 +187,9 @@ int ovm_profile_read(OvmHandle* h, float* ms /* [OVM_PROF_NCAT] */, int32_t* lau
 /* --- host-side helpers (no GPU needed) -------------------------------------------------------- */
 /* dinov2 interpolate_pos_encoding (hub: offset 0.1, bicubic, no antialias): pos [1+M*M][D] -> out [1+G*G][D] */
 int ovm_host_interp_pos_embed(const float* pos, int32_t M, int32_t D, int32_t G, float* out);
+/* resize_pos_embed of the CLIP tower (reference cubercnn/modeling/backbone/clip.py:98-133): F.interpolate(size=(G,G), bicubic,
+ * align_corners=False, antialias=True) of the patch rows, class row kept: pos [1+M*M][D] -> out [1+G*G][D] */
+int ovm_host_resize_pos_embed_aa(const float* pos, int32_t M, int32_t D, int32_t G, float* out);
 /* InferenceSampler contiguous shard [begin,end) of rank (reference cubercnn/data/build.py:320) */
 int ovm_host_shard_range(int64_t n_items, int32_t rank, int32_t world, int64_t* begin, int64_t* end);
 

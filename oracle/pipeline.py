@@ -13,12 +13,13 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
-from . import heads, rpn, sfp, vit
+from . import clip_vit, heads, rpn, sfp, vit
 
 
 @dataclass
 class OracleParams:
     model_name: str = "vitl14"
+    tower: str = "dinov2"                                           # 'dinov2' (build_dino_backbone) | 'clip' (build_clip_backbone)
     embed_dim: int = 1024
     depth: int = 24
     heads: int = 16
@@ -62,6 +63,10 @@ def preprocess(batched_inputs: List[Dict], P: OracleParams) -> Tuple[torch.Tenso
 
 
 def backbone(sd, images: torch.Tensor, P: OracleParams, prompt_depth=None) -> Dict[str, torch.Tensor]:
+    if P.tower == "clip":
+        # detectron2's SimpleFeaturePyramid.forward(x) has no depth argument: the fork's rcnn3d.py:97 call with one raises
+        assert prompt_depth is None, "the CLIP backbone takes no prompt_depth (SURVEY.md 0.4)"
+        return sfp.sfp4_forward(sd, clip_vit.clip_backbone_forward(sd, images, P.heads, P.depth))
     dense = vit.dino_backbone_forward(sd, images, P.heads, P.depth, prompt_depth, P.use_depth_fusion)
     return sfp.sfp_forward(sd, dense)
 
@@ -87,7 +92,7 @@ def inference(sd, batched_inputs: List[Dict], P: OracleParams, prompt_depth: Opt
     ratios = [b["height"] / s[0] for b, s in zip(batched_inputs, sizes)]            # rcnn3d.py:92
     Ks = [torch.as_tensor(b["K"], dtype=torch.float32) for b in batched_inputs]      # :95
     feats_d = backbone(sd, images, P, prompt_depth)
-    feats = [feats_d[k] for k in ("p2", "p3", "p4")]
+    feats = [feats_d[k] for k in sorted(feats_d)]
     scales = [1.0 / s for s in P.strides]
     aux = {"features": feats_d}
     if given_boxes is not None:

@@ -39,7 +39,9 @@ class DetectionCheckpointer:
             spec = path[len("synthetic://"):]
             name, _, q = spec.partition("?")
             seed = int(q.split("=")[1]) if q.startswith("seed=") else 0
-            sd = synth_state_dict(name or self.model.cfg.MODEL.DINO.MODEL_NAME,
+            cfg = self.model.cfg
+            default = cfg.MODEL.CLIP.ARCH if cfg.MODEL.BACKBONE.NAME == "build_clip_backbone" else cfg.MODEL.DINO.MODEL_NAME
+            sd = synth_state_dict(name or default,
                                   num_classes=self.model.cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=seed)
         else:
             if not os.path.isfile(path):

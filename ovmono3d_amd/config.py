@@ -233,6 +233,9 @@ def get_cfg_defaults(cfg: CfgNode) -> CfgNode:
 
     cfg.MODEL.DINO = CfgNode(dict(NAME="dinov2", MODEL_NAME="vitb14", OUTPUT="dense", LAYER=-1,
                                   RETURN_MULTILAYER=False, USE_DEPTH_FUSION=True))
+    # CLIP image tower behind the same pyramid and heads (reference config.py:100-105, backbone/clip.py; MODEL.BACKBONE.NAME
+    # 'build_clip_backbone'); ARCH names follow open_clip
+    cfg.MODEL.CLIP = CfgNode(dict(ARCH="ViT-B-16", CHECKPOINT="openai", OUTPUT="dense", LAYER=-1, RETURN_MULTILAYER=False))
 
     H = CfgNode()
     H.NAME = "CubeHead"

@@ -34,6 +34,15 @@ struct SfpStage {              // 1x1 conv + LN, 3x3 conv + LN
   PackedLinear c1, c3; float *n1g, *n1b, *n3g, *n3b;
 };
 
+struct FpnLevel {              // one output level of the simple feature pyramid, finest first ("p2", "p3", ...)
+  int side = 0; float stride = 0.f;
+  SfpStage st;
+  float* T1 = nullptr;         // fp32 conv output (1x1, then reused by the 3x3)
+  Split pad;                   // zero-bordered LN(1x1) image: the implicit-GEMM input of the 3x3
+  float* p = nullptr;          // the level's feature map, NHWC fp32
+  Split rpad;                  // zero-bordered fp16 copy of p (RPN conv input), when the checkpoint has an RPN
+};
+
 }  // namespace
 
 struct OvmHandle {
@@ -42,23 +51,25 @@ struct OvmHandle {
   std::string err;
   std::vector<void*> allocs;
   int G = 0, G2 = 0, T = 0, Tpad = 0, D = 0, C = 0, Kpe = 640, npass = 1;
+  int patch = 14, nlev = 3;          // by tower: 14 / 3 levels (DINOv2, scales 2 1 0.5) or 16 / 4 levels (CLIP, scales 4 2 1 0.5)
+  float ln_eps = 1e-6f;             // LayerNorm eps of the ViT blocks (1e-6 dinov2, 1e-5 open_clip)
+  int mlp_act = 0;                  // fc1 activation: 0 erf-GELU, 3 QuickGELU
   int roiK = 0;
   // weights
   PackedLinear pe; float *cls = nullptr, *pos = nullptr;
+  float *lnpre_g = nullptr, *lnpre_b = nullptr;                 // open_clip ln_pre
   std::vector<Layer> layers;
   PackedLinear dfuse; bool has_dfuse = false;
-  PackedLinear convt; SfpStage s2, s3, s4;
+  PackedLinear convt;                                           // ConvT D -> D/2 (first layer of the scale-2 and scale-4 stages... per stage)
+  PackedLinear convt4a, convt4b; float *up_ln_g = nullptr, *up_ln_b = nullptr;   // scale-4 stage: ConvT D -> D/2, LN, GELU, ConvT D/2 -> D/4
+  FpnLevel lv[kMaxLevels];
   PackedLinear cube_fc1, cube_fc2, cube_out;
   PackedLinear box_fc1, box_fc2, box_out; bool has_box = false;
   PackedLinear rpn_conv, rpn_out; bool has_rpn = false;
   // workspace
   float* X = nullptr;
-  Split PA, HN, AO, F1, Q, Kx, Vt, DT, DT4, DF, CT;
+  Split PA, HN, AO, F1, Q, Kx, Vt, DT, DT4, DF, CT, CT4a, CT4b;
   float *dtok = nullptr, *FUS = nullptr;
-  float *T2 = nullptr, *T3 = nullptr, *T4 = nullptr;           // 1x1 / 3x3 conv fp32 outputs (reused)
-  Split P2pad, P3pad, P4pad;                                    // zero-bordered LN(1x1) images
-  float *p2 = nullptr, *p3 = nullptr, *p4 = nullptr;            // final features NHWC fp32
-  Split R2pad, R3pad, R4pad;                                    // zero-bordered fp16 copies of p2..p4 (RPN conv input)
   Split RF, H1, H2; float* HO = nullptr;
   float* rec = nullptr; int* keep = nullptr;
   int *d_bidx = nullptr;
@@ -252,6 +263,29 @@ int pack_concat(OvmHandle* h, const WeightMap& wm, const std::vector<std::pair<s
   return upload_vec(h, b, &out->bias);
 }
 
+// nn.Linear stored as bare parameters (nn.MultiheadAttention in_proj_weight / in_proj_bias)
+int pack_linear_named(OvmHandle* h, const WeightMap& wm, const std::string& wkey, const std::string& bkey, int N, int K, PackedLinear* out) {
+  const float* w; int r = get_host(h, wm, wkey, (int64_t)N * K, &w);
+  if (r) return r;
+  std::vector<float> v(w, w + (size_t)N * K);
+  r = upload_packed(h, v, N, K, K, out);
+  if (r) return r;
+  return upload_f32(h, wm, bkey, N, &out->bias);
+}
+
+// ConvTranspose2d k2 s2 weight [Cin][Cout][2][2] -> GEMM rows [(a*2+b)*Cout + co][ci]; bias [Cout] (applied per co in EPI_CONVT)
+int pack_convt(OvmHandle* h, const WeightMap& wm, const std::string& prefix, int Cin, int Cout, PackedLinear* out) {
+  const float* w; int r = get_host(h, wm, prefix + ".weight", (int64_t)Cin * Cout * 4, &w);
+  if (r) return r;
+  std::vector<float> v((size_t)4 * Cout * Cin);
+  for (int ci = 0; ci < Cin; ++ci)
+    for (int co = 0; co < Cout; ++co)
+      for (int q = 0; q < 4; ++q) v[((size_t)q * Cout + co) * Cin + ci] = w[((size_t)ci * Cout + co) * 4 + q];
+  r = upload_packed(h, v, 4 * Cout, Cin, Cin, out);
+  if (r) return r;
+  return upload_f32(h, wm, prefix + ".bias", Cout, &out->bias);
+}
+
 int pack_sfp_stage(OvmHandle* h, const WeightMap& wm, const std::string& p1, const std::string& p3, int Cin, SfpStage* s) {
   const int C = h->C;
   int r = pack_conv(h, wm, p1, C, Cin, 1, &s->c1, false); if (r) return r;
@@ -316,7 +350,18 @@ namespace ovm { void set_use_gemm256(int v) { g_use_gemm256 = v; } }
 
 extern "C" {
 
-const char* ovm_version(void) { return "libovm3d 0.1 (gfx950)"; }
+const char* ovm_version(void) { return "libovm3d 0.2 (gfx950)"; }
+
+int ovm_abi_sizeof(const char* name) {
+  if (!name) return -1;
+  const std::string n(name);
+  if (n == "OvmConfig") return (int)sizeof(OvmConfig);
+  if (n == "OvmTensor") return (int)sizeof(OvmTensor);
+  if (n == "OvmImage") return (int)sizeof(OvmImage);
+  if (n == "OvmDet3D") return (int)sizeof(OvmDet3D);
+  if (n == "OvmGdinoConfig") return (int)sizeof(OvmGdinoConfig);
+  return -1;
+}
 
 const char* ovm_last_error(const OvmHandle* h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -390,44 +435,136 @@ int ovm_host_interp_pos_embed(const float* pos, int32_t M, int32_t D, int32_t G,
   return OVM_OK;
 }
 
+// F.interpolate(pos[1,D,M,M], size=(G,G), mode="bicubic", align_corners=False, antialias=True) of the patch part of an
+// open_clip positional embedding [1 + M*M][D], class row kept (reference clip.py:98-133). PyTorch's antialiased path is a
+// separable, NORMALISED filter (not the clamped 4-tap one above): per output index, taps j in [xmin, xmin + xsize) with
+// xmin = max(int(center - support + 0.5), 0), xsize = min(int(center + support + 0.5), M) - xmin, center = scale (i + 0.5),
+// scale = M / G, support = 2 max(scale, 1), weight = cubic_{a = -0.5}((j - center + 0.5) / max(scale, 1)) / sum; all in fp32,
+// width pass first, then height (ATen UpSampleKernel.cpp, _compute_indices_min_size_weights_aa). Returns pos unchanged when
+// G == M (:117-118).
+int ovm_host_resize_pos_embed_aa(const float* pos, int32_t M, int32_t D, int32_t G, float* out) {
+  if (M <= 0 || D <= 0 || G <= 0) return OVM_ERR_INVALID;
+  memcpy(out, pos, (size_t)D * 4);
+  if (G == M) { memcpy(out + D, pos + D, (size_t)M * M * D * 4); return OVM_OK; }
+  const float scale = (float)M / (float)G;
+  const float support = scale >= 1.f ? 2.f * scale : 2.f;
+  const float invscale = scale >= 1.f ? 1.f / scale : 1.f;
+  const int max_taps = (int)ceilf(support) * 2 + 1;
+  auto filt = [](float x) {
+    const float a = -0.5f;
+    x = fabsf(x);
+    if (x < 1.f) return ((a + 2.f) * x - (a + 3.f)) * x * x + 1.f;
+    if (x < 2.f) return ((a * x - 5.f * a) * x + 8.f * a) * x - 4.f * a;
+    return 0.f;
+  };
+  std::vector<int> xmin(G), xsize(G);
+  std::vector<float> wt((size_t)G * max_taps, 0.f);
+  for (int i = 0; i < G; ++i) {
+    const float center = scale * ((float)i + 0.5f);
+    int lo = (int)(center - support + 0.5f); if (lo < 0) lo = 0;
+    int hi = (int)(center + support + 0.5f); if (hi > M) hi = M;
+    int n = hi - lo; if (n < 0) n = 0; if (n > max_taps) n = max_taps;
+    xmin[i] = lo; xsize[i] = n;
+    float total = 0.f;
+    for (int j = 0; j < n; ++j) { const float w = filt(((float)(j + lo) - center + 0.5f) * invscale); wt[(size_t)i * max_taps + j] = w; total += w; }
+    const float inv = total != 0.f ? 1.f / total : 0.f;
+    for (int j = 0; j < n; ++j) wt[(size_t)i * max_taps + j] *= inv;
+  }
+  const float* src = pos + D;                              // [M][M][D]
+  std::vector<float> tmp((size_t)M * G * D);               // width pass: [M][G][D]
+  for (int y = 0; y < M; ++y)
+    for (int ox = 0; ox < G; ++ox) {
+      float* o = &tmp[((size_t)y * G + ox) * D];
+      const float* w = &wt[(size_t)ox * max_taps];
+      for (int d = 0; d < D; ++d) {
+        float t = xsize[ox] > 0 ? src[((size_t)y * M + xmin[ox]) * D + d] * w[0] : 0.f;
+        for (int j = 1; j < xsize[ox]; ++j) t += src[((size_t)y * M + xmin[ox] + j) * D + d] * w[j];
+        o[d] = t;
+      }
+    }
+  float* dst = out + D;
+  for (int oy = 0; oy < G; ++oy) {
+    const float* w = &wt[(size_t)oy * max_taps];
+    for (int ox = 0; ox < G; ++ox) {
+      float* o = dst + ((size_t)oy * G + ox) * D;
+      for (int d = 0; d < D; ++d) {
+        float t = xsize[oy] > 0 ? tmp[((size_t)xmin[oy] * G + ox) * D + d] * w[0] : 0.f;
+        for (int j = 1; j < xsize[oy]; ++j) t += tmp[((size_t)(xmin[oy] + j) * G + ox) * D + d] * w[j];
+        o[d] = t;
+      }
+    }
+  }
+  return OVM_OK;
+}
+
 int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights, int32_t device, OvmHandle** out) {
   if (!cfg || !out) return OVM_ERR_INVALID;
   OvmHandle* h = new OvmHandle();
   *out = h;
   h->cfg = *cfg; h->device = device;
   const OvmConfig& c = h->cfg;
-  if (c.canvas % 14 != 0 || c.embed_dim % 128 != 0 || c.embed_dim != c.heads * 64 || (c.precision != 1 && c.precision != 3) ||
-      c.fpn_channels % 64 != 0 || c.max_batch < 1 || c.max_rois < 1) {
-    h->err = "invalid config (canvas %14, embed_dim = heads*64 and %128, precision in {1,3}, fpn_channels %64)";
+  const bool clip = c.tower == OVM_TOWER_CLIP;
+  if (c.tower != OVM_TOWER_DINOV2 && !clip) { h->err = "invalid config (tower)"; return OVM_ERR_INVALID; }
+  h->patch = clip ? 16 : 14; h->nlev = clip ? 4 : 3;
+  h->ln_eps = clip ? 1e-5f : 1e-6f; h->mlp_act = clip ? 3 : 0;
+  h->Kpe = clip ? 768 : 640;
+  // the scale-4 stage needs D/4 channels in 64-wide k-steps
+  if (c.canvas % h->patch != 0 || c.embed_dim % 128 != 0 || c.embed_dim != c.heads * 64 || (c.precision != 1 && c.precision != 3) ||
+      c.fpn_channels % 64 != 0 || c.max_batch < 1 || c.max_rois < 1 || (clip && c.embed_dim % 256 != 0)) {
+    h->err = "invalid config (canvas % patch, embed_dim = heads*64 and %128 (%256 for 4-level towers), precision in {1,3}, fpn_channels %64)";
     return OVM_ERR_INVALID;
   }
   HCHECK(h, hipSetDevice(device));
   h->npass = c.precision;
   h->D = c.embed_dim; h->C = c.fpn_channels;
-  h->G = c.canvas / 14; h->G2 = h->G * h->G; h->T = h->G2 + 1; h->Tpad = (h->T + 63) / 64 * 64;
+  h->G = c.canvas / h->patch; h->G2 = h->G * h->G; h->T = h->G2 + 1; h->Tpad = (h->T + 63) / 64 * 64;
   const int D = h->D, C = h->C, G = h->G, G2 = h->G2, T = h->T, L = c.depth, B = c.max_batch, R = c.max_rois;
   WeightMap wm;
   for (int i = 0; i < n_weights; ++i) wm.m[weights[i].name] = &weights[i];
   int r;
-  const std::string V = "backbone.net.vit.";
-  // ---- patch embed: [D][3][14][14] -> [D][(py*14+px)*3 + c], K padded 588 -> 640
+  const int P = h->patch, PP = P * P;
+  const std::string V = clip ? "backbone.net.visual." : "backbone.net.vit.";
+  // ---- patch embed: [D][3][P][P] -> [D][(py*P+px)*3 + c]; P = 14: K padded 588 -> 640
   {
-    const float* w; r = get_host(h, wm, V + "patch_embed.proj.weight", (int64_t)D * 588, &w); if (r) return r;
-    std::vector<float> v((size_t)D * 588);
+    const float* w; r = get_host(h, wm, V + (clip ? "conv1.weight" : "patch_embed.proj.weight"), (int64_t)D * 3 * PP, &w); if (r) return r;
+    std::vector<float> v((size_t)D * 3 * PP);
     for (int o = 0; o < D; ++o)
       for (int ch = 0; ch < 3; ++ch)
-        for (int t = 0; t < 196; ++t) v[(size_t)o * 588 + t * 3 + ch] = w[((size_t)o * 3 + ch) * 196 + t];
-    r = upload_packed(h, v, D, 588, h->Kpe, &h->pe); if (r) return r;
-    r = upload_f32(h, wm, V + "patch_embed.proj.bias", D, &h->pe.bias); if (r) return r;
-    r = upload_f32(h, wm, V + "cls_token", D, &h->cls); if (r) return r;
-    const float* pos; r = get_host(h, wm, V + "pos_embed", (int64_t)(1 + c.pos_grid * c.pos_grid) * D, &pos); if (r) return r;
+        for (int t = 0; t < PP; ++t) v[(size_t)o * 3 * PP + t * 3 + ch] = w[((size_t)o * 3 + ch) * PP + t];
+    r = upload_packed(h, v, D, 3 * PP, h->Kpe, &h->pe); if (r) return r;
+    const float* pos;
     std::vector<float> pi((size_t)T * D);
-    r = ovm_host_interp_pos_embed(pos, c.pos_grid, D, G, pi.data()); if (r) return r;
+    if (clip) {                                            // conv1 has no bias (open_clip VisionTransformer)
+      h->pe.bias = nullptr;
+      r = upload_f32(h, wm, V + "class_embedding", D, &h->cls); if (r) return r;
+      r = get_host(h, wm, V + "positional_embedding", (int64_t)(1 + c.pos_grid * c.pos_grid) * D, &pos); if (r) return r;
+      r = ovm_host_resize_pos_embed_aa(pos, c.pos_grid, D, G, pi.data()); if (r) return r;
+      r = upload_f32(h, wm, V + "ln_pre.weight", D, &h->lnpre_g); if (r) return r;
+      r = upload_f32(h, wm, V + "ln_pre.bias", D, &h->lnpre_b); if (r) return r;
+    } else {
+      r = upload_f32(h, wm, V + "patch_embed.proj.bias", D, &h->pe.bias); if (r) return r;
+      r = upload_f32(h, wm, V + "cls_token", D, &h->cls); if (r) return r;
+      r = get_host(h, wm, V + "pos_embed", (int64_t)(1 + c.pos_grid * c.pos_grid) * D, &pos); if (r) return r;
+      r = ovm_host_interp_pos_embed(pos, c.pos_grid, D, G, pi.data()); if (r) return r;
+    }
     r = upload_vec(h, pi, &h->pos); if (r) return r;
   }
   h->layers.resize(L);
   for (int l = 0; l < L; ++l) {
     Layer& y = h->layers[l];
+    if (clip) {                                            // open_clip ResidualAttentionBlock: ln_1, attn (nn.MultiheadAttention), ln_2, mlp
+      const std::string Pq = V + "transformer.resblocks." + std::to_string(l) + ".";
+      if ((r = upload_f32(h, wm, Pq + "ln_1.weight", D, &y.ln1g))) return r;
+      if ((r = upload_f32(h, wm, Pq + "ln_1.bias", D, &y.ln1b))) return r;
+      if ((r = upload_f32(h, wm, Pq + "ln_2.weight", D, &y.ln2g))) return r;
+      if ((r = upload_f32(h, wm, Pq + "ln_2.bias", D, &y.ln2b))) return r;
+      y.ls1 = y.ls2 = nullptr;                             // no LayerScale
+      if ((r = pack_linear_named(h, wm, Pq + "attn.in_proj_weight", Pq + "attn.in_proj_bias", 3 * D, D, &y.qkv))) return r;
+      if ((r = pack_linear(h, wm, Pq + "attn.out_proj", D, D, &y.proj))) return r;
+      if ((r = pack_linear(h, wm, Pq + "mlp.c_fc", 4 * D, D, &y.fc1))) return r;
+      if ((r = pack_linear(h, wm, Pq + "mlp.c_proj", D, 4 * D, &y.fc2))) return r;
+      continue;
+    }
     const std::string P = V + "blocks." + std::to_string(l) + ".";
     if ((r = upload_f32(h, wm, P + "norm1.weight", D, &y.ln1g))) return r;
     if ((r = upload_f32(h, wm, P + "norm1.bias", D, &y.ln1b))) return r;
@@ -440,23 +577,34 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
     if ((r = pack_linear(h, wm, P + "mlp.fc1", 4 * D, D, &y.fc1))) return r;
     if ((r = pack_linear(h, wm, P + "mlp.fc2", D, 4 * D, &y.fc2))) return r;
   }
-  h->has_dfuse = c.use_depth_fusion && wm.get("backbone.net.depth_fusion.weight");
+  h->has_dfuse = !clip && c.use_depth_fusion && wm.get("backbone.net.depth_fusion.weight");
   if (h->has_dfuse) {
     if ((r = pack_linear(h, wm, "backbone.net.depth_fusion", D, D + 1, &h->dfuse, true, D + 64))) return r;
   }
-  // ---- SFP: ConvT [Cin=D][Cout=D/2][2][2] -> [(a*2+b)*Cout + co][c]
+  // ---- SFP (detectron2 SimpleFeaturePyramid; module names simfp_{log2 stride}.{index in the stage's Sequential}):
+  //   scale 4   : ConvT(D, D/2) . LN . GELU . ConvT(D/2, D/4) . conv1x1+LN . conv3x3+LN        (4-level towers only)
+  //   scale 2   : ConvT(D, D/2) . conv1x1+LN . conv3x3+LN
+  //   scale 1   : conv1x1+LN . conv3x3+LN
+  //   scale 0.5 : MaxPool2 . conv1x1+LN . conv3x3+LN
   {
-    const int Co = D / 2;
-    const float* w; r = get_host(h, wm, "backbone.simfp_2.0.weight", (int64_t)D * Co * 4, &w); if (r) return r;
-    std::vector<float> v((size_t)4 * Co * D);
-    for (int ci = 0; ci < D; ++ci)
-      for (int co = 0; co < Co; ++co)
-        for (int q = 0; q < 4; ++q) v[((size_t)q * Co + co) * D + ci] = w[((size_t)ci * Co + co) * 4 + q];
-    r = upload_packed(h, v, 4 * Co, D, D, &h->convt); if (r) return r;
-    r = upload_f32(h, wm, "backbone.simfp_2.0.bias", Co, &h->convt.bias); if (r) return r;
-    if ((r = pack_sfp_stage(h, wm, "backbone.simfp_2.1", "backbone.simfp_2.2", Co, &h->s2))) return r;
-    if ((r = pack_sfp_stage(h, wm, "backbone.simfp_3.0", "backbone.simfp_3.1", D, &h->s3))) return r;
-    if ((r = pack_sfp_stage(h, wm, "backbone.simfp_4.1", "backbone.simfp_4.2", D, &h->s4))) return r;
+    const int first = 2;                                                // int(log2(7)) = int(log2(4)) = 2
+    int li = 0;
+    auto sname = [&](int lvl, int idx) { return "backbone.simfp_" + std::to_string(first + lvl) + "." + std::to_string(idx); };
+    if (clip) {
+      if ((r = pack_convt(h, wm, sname(li, 0), D, D / 2, &h->convt4a))) return r;
+      if ((r = upload_f32(h, wm, sname(li, 1) + ".weight", D / 2, &h->up_ln_g))) return r;
+      if ((r = upload_f32(h, wm, sname(li, 1) + ".bias", D / 2, &h->up_ln_b))) return r;
+      if ((r = pack_convt(h, wm, sname(li, 3), D / 2, D / 4, &h->convt4b))) return r;
+      if ((r = pack_sfp_stage(h, wm, sname(li, 4), sname(li, 5), D / 4, &h->lv[li].st))) return r;
+      h->lv[li].side = 4 * G; h->lv[li].stride = (float)P / 4.f; ++li;
+    }
+    if ((r = pack_convt(h, wm, sname(li, 0), D, D / 2, &h->convt))) return r;
+    if ((r = pack_sfp_stage(h, wm, sname(li, 1), sname(li, 2), D / 2, &h->lv[li].st))) return r;
+    h->lv[li].side = 2 * G; h->lv[li].stride = (float)P / 2.f; ++li;
+    if ((r = pack_sfp_stage(h, wm, sname(li, 0), sname(li, 1), D, &h->lv[li].st))) return r;
+    h->lv[li].side = G; h->lv[li].stride = (float)P; ++li;
+    if ((r = pack_sfp_stage(h, wm, sname(li, 1), sname(li, 2), D, &h->lv[li].st))) return r;
+    h->lv[li].side = G / 2; h->lv[li].stride = (float)P * 2.f; ++li;
   }
   // ---- heads
   const int res = c.pooler_res, F = c.fc_dim;
@@ -499,19 +647,17 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
   }
   const int G2x = 2 * G, G4 = G / 2;
   if ((r = salloc(h, &h->CT, (size_t)B * G2x * G2x * (D / 2)))) return r;
-  if ((r = dalloc(h, &h->T2, (size_t)B * G2x * G2x * C))) return r;
-  if ((r = dalloc(h, &h->T3, MP * C))) return r;
-  if ((r = dalloc(h, &h->T4, (size_t)B * G4 * G4 * C))) return r;
-  if ((r = salloc(h, &h->P2pad, (size_t)B * (G2x + 2) * (G2x + 2) * C, true))) return r;
-  if ((r = salloc(h, &h->P3pad, (size_t)B * (G + 2) * (G + 2) * C, true))) return r;
-  if ((r = salloc(h, &h->P4pad, (size_t)B * (G4 + 2) * (G4 + 2) * C, true))) return r;
-  if ((r = dalloc(h, &h->p2, (size_t)B * G2x * G2x * C))) return r;
-  if ((r = dalloc(h, &h->p3, MP * C))) return r;
-  if ((r = dalloc(h, &h->p4, (size_t)B * G4 * G4 * C))) return r;
-  if (h->has_rpn) {
-    if ((r = salloc(h, &h->R2pad, (size_t)B * (G2x + 2) * (G2x + 2) * C, true))) return r;
-    if ((r = salloc(h, &h->R3pad, (size_t)B * (G + 2) * (G + 2) * C, true))) return r;
-    if ((r = salloc(h, &h->R4pad, (size_t)B * (G4 + 2) * (G4 + 2) * C, true))) return r;
+  if (clip) {
+    if ((r = salloc(h, &h->CT4a, (size_t)B * G2x * G2x * (D / 2)))) return r;
+    if ((r = salloc(h, &h->CT4b, (size_t)B * 4 * G2x * G2x * (D / 4)))) return r;
+  }
+  for (int l = 0; l < h->nlev; ++l) {
+    FpnLevel& f = h->lv[l];
+    const size_t px = (size_t)B * f.side * f.side, pxp = (size_t)B * (f.side + 2) * (f.side + 2);
+    if ((r = dalloc(h, &f.T1, px * C))) return r;
+    if ((r = salloc(h, &f.pad, pxp * C, true))) return r;
+    if ((r = dalloc(h, &f.p, px * C))) return r;
+    if (h->has_rpn && (r = salloc(h, &f.rpad, pxp * C, true))) return r;
   }
   const size_t RR = (size_t)R * B;
   if ((r = salloc(h, &h->RF, RR * h->roiK))) return r;
@@ -527,7 +673,9 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
   HCHECK(h, hipHostMalloc((void**)&h->h_meta, sizeof(ImageMeta) * B));
   if (h->has_rpn && h->has_box) {
     std::vector<void*> extra;
-    r = det2d_alloc(&h->det, B, G, C, c.num_classes, R, c.rpn_pre_topk, c.rpn_post_topk, c.detections_per_image, &extra);
+    int sides[kMaxLevels];
+    for (int l = 0; l < h->nlev; ++l) sides[l] = h->lv[l].side;
+    r = det2d_alloc(&h->det, B, h->nlev, sides, C, c.num_classes, R, c.rpn_pre_topk, c.rpn_post_topk, c.detections_per_image, &extra);
     for (void* p : extra) h->allocs.push_back(p);
     if (r) { h->err = "det2d workspace allocation failed"; return r; }
   }
@@ -535,24 +683,32 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
   return OVM_OK;
 }
 
-static int sfp_branch(OvmHandle* h, const Split& in, int lda, int Bn, int Hs, const SfpStage& st, float* T1, const Split& pad,
-                      float* pout, const Split* rpad, hipStream_t s) {
-  const int C = h->C, M = Bn * Hs * Hs;
+static int sfp_branch(OvmHandle* h, const Split& in, int lda, int Bn, const FpnLevel& f, hipStream_t s) {
+  const int C = h->C, Hs = f.side, M = Bn * Hs * Hs;
+  const SfpStage& st = f.st;
   GemmParams p = gp_base(in, lda, st.c1, M);
-  p.C = T1; p.ldc = C;
+  p.C = f.T1; p.ldc = C;
   KCHECK(h, gemm(h, p, EPI_STORE, A_ROWMAJOR, s));
   LnOut o; memset(&o, 0, sizeof(o));
-  o.hi = pad.hi; o.lo = pad.lo; o.ld = C; o.padH = Hs; o.padW = Hs;
-  KCHECK(h, launch_ln_rows(T1, C, M, C, st.n1g, st.n1b, 1e-6f, o, s));
+  o.hi = f.pad.hi; o.lo = f.pad.lo; o.ld = C; o.padH = Hs; o.padW = Hs;
+  KCHECK(h, launch_ln_rows(f.T1, C, M, C, st.n1g, st.n1b, 1e-6f, o, s));
   GemmParams q; memset(&q, 0, sizeof(q));
-  q.Ahi = pad.hi; q.Alo = pad.lo; q.Whi = st.c3.w.hi; q.Wlo = st.c3.w.lo;
+  q.Ahi = f.pad.hi; q.Alo = f.pad.lo; q.Whi = st.c3.w.hi; q.Wlo = st.c3.w.lo;
   q.M = M; q.N = C; q.K = 9 * C; q.cH = Hs; q.cW = Hs; q.cC = C;
-  q.C = T1; q.ldc = C;                                   // 1x1 output already consumed by the LN above
+  q.C = f.T1; q.ldc = C;                                 // 1x1 output already consumed by the LN above
   KCHECK(h, gemm(h, q, EPI_STORE, A_CONV3X3, s));
   LnOut o2; memset(&o2, 0, sizeof(o2));
-  o2.f32 = pout; o2.ldf = C;
-  if (rpad && rpad->hi) { o2.hi = rpad->hi; o2.lo = rpad->lo; o2.ld = C; o2.padH = Hs; o2.padW = Hs; }
-  KCHECK(h, launch_ln_rows(T1, C, M, C, st.n3g, st.n3b, 1e-6f, o2, s));
+  o2.f32 = f.p; o2.ldf = C;
+  if (f.rpad.hi) { o2.hi = f.rpad.hi; o2.lo = f.rpad.lo; o2.ld = C; o2.padH = Hs; o2.padW = Hs; }
+  KCHECK(h, launch_ln_rows(f.T1, C, M, C, st.n3g, st.n3b, 1e-6f, o2, s));
+  return OVM_OK;
+}
+
+// ConvTranspose2d k2 s2 as a GEMM over the source pixels (EPI_CONVT scatters the 2x2 outputs): [Bn][Gs][Gs][Cin] -> [Bn][2Gs][2Gs][Cout]
+static int convt_up(OvmHandle* h, const Split& in, int Cin, int Bn, int Gs, const PackedLinear& w, const Split& out, hipStream_t s) {
+  GemmParams p = gp_base(in, Cin, w, Bn * Gs * Gs);
+  p.Ohi = out.hi; p.Olo = out.lo; p.G = Gs; p.Cout = w.N / 4;
+  KCHECK(h, gemm(h, p, EPI_CONVT, A_ROWMAJOR, s));
   return OVM_OK;
 }
 
@@ -574,7 +730,12 @@ int ovm_backbone_forward(OvmHandle* h, const OvmImage* images, int32_t B, const 
   HCHECK(h, hipMemcpyAsync(h->d_meta, h->h_meta, sizeof(ImageMeta) * B, hipMemcpyHostToDevice, s));
   h->lastB = B;
   // ---- patch embed (+ preprocess) ----
-  KCHECK(h, launch_patch_gather(h->d_imgs, B, G, h->Kpe, c.pixel_mean, c.pixel_std, h->PA.hi, h->PA.lo, s));
+  if (prompt_depth && c.tower != OVM_TOWER_DINOV2) {
+    // detectron2's SimpleFeaturePyramid.forward(x) takes no depth; the fork's RCNN3D passes one to every backbone and
+    // would raise a TypeError here: refuse rather than silently drop it
+    h->err = "prompt_depth is only defined for the DINOv2 tower (depth_fusion, dino.py:91-105)"; return OVM_ERR_INVALID;
+  }
+  KCHECK(h, launch_patch_gather(h->d_imgs, B, G, h->patch, h->Kpe, c.pixel_mean, c.pixel_std, h->PA.hi, h->PA.lo, s));
   KCHECK(h, launch_cls_init(h->X, h->cls, h->pos, B, T, D, s));
   {
     GemmParams p = gp_base(h->PA, h->Kpe, h->pe, B * G2);
@@ -582,11 +743,16 @@ int ovm_backbone_forward(OvmHandle* h, const OvmImage* images, int32_t B, const 
     KCHECK(h, gemm(h, p, EPI_PATCH, A_ROWMAJOR, s));
   }
   const int M = B * T;
+  const float eps = h->ln_eps;
+  if (h->lnpre_g) {                                        // open_clip: x = ln_pre(x + pos) (reference clip.py:78-79), in place
+    LnOut o; memset(&o, 0, sizeof(o)); o.f32 = h->X; o.ldf = D;
+    ProfScope ps(h, OVM_PROF_LN, s); KCHECK(h, launch_ln_rows(h->X, D, M, D, h->lnpre_g, h->lnpre_b, eps, o, s));
+  }
   for (int l = 0; l < L; ++l) {
     const Layer& y = h->layers[l];
     const int il = h->npass == 3 ? 1 : 0, am = il ? 2 : 1;    // activations of the blocks: interleaved split images in f16x3 mode
     LnOut o; memset(&o, 0, sizeof(o)); o.hi = h->HN.hi; o.lo = h->HN.lo; o.ld = am * D; o.il = il;
-    { ProfScope ps(h, OVM_PROF_LN, s); KCHECK(h, launch_ln_rows(h->X, D, M, D, y.ln1g, y.ln1b, 1e-6f, o, s)); }
+    { ProfScope ps(h, OVM_PROF_LN, s); KCHECK(h, launch_ln_rows(h->X, D, M, D, y.ln1g, y.ln1b, eps, o, s)); }
     {
       GemmParams p = gp_base(h->HN, am * D, y.qkv, M); p.a_il = il;
       p.Qhi = h->Q.hi; p.Qlo = h->Q.lo; p.Khi = h->Kx.hi; p.Klo = h->Kx.lo; p.Vhi = h->Vt.hi; p.Vlo = h->Vt.lo;
@@ -605,10 +771,10 @@ int ovm_backbone_forward(OvmHandle* h, const OvmImage* images, int32_t B, const 
       p.gamma = y.ls1; p.X = h->X; p.ldx = D;
       KCHECK(h, gemm(h, p, EPI_RESID, A_ROWMAJOR, s, OVM_PROF_PROJ));
     }
-    { ProfScope ps(h, OVM_PROF_LN, s); KCHECK(h, launch_ln_rows(h->X, D, M, D, y.ln2g, y.ln2b, 1e-6f, o, s)); }
+    { ProfScope ps(h, OVM_PROF_LN, s); KCHECK(h, launch_ln_rows(h->X, D, M, D, y.ln2g, y.ln2b, eps, o, s)); }
     {
       GemmParams p = gp_base(h->HN, am * D, y.fc1, M); p.a_il = il;
-      p.Ohi = h->F1.hi; p.Olo = h->F1.lo; p.ldo = am * 4 * D; p.o_il = il;
+      p.Ohi = h->F1.hi; p.Olo = h->F1.lo; p.ldo = am * 4 * D; p.o_il = il; p.relu = h->mlp_act;
       KCHECK(h, gemm(h, p, EPI_GELU, A_ROWMAJOR, s, OVM_PROF_FC1));
     }
     {
@@ -629,31 +795,44 @@ int ovm_backbone_forward(OvmHandle* h, const OvmImage* images, int32_t B, const 
   }
   // ---- dense tokens (no final LayerNorm: reference dino.py:88-110) ----
   KCHECK(h, launch_tokens_cast(h->X, B, T, G2, D, D, nullptr, h->DT.hi, h->DT.lo, s));
-  // ---- SFP (reference dino.py:143-152,208-224; stages nohup.out:565-596) ----
-  const bool rp = h->has_rpn;
-  KCHECK(h, sfp_branch(h, h->DT, D, B, G, h->s3, h->T3, h->P3pad, h->p3, rp ? &h->R3pad : nullptr, s));
-  KCHECK(h, launch_maxpool2(h->DT.hi, h->DT.lo, B, G, D, h->DT4.hi, h->DT4.lo, s));
-  KCHECK(h, sfp_branch(h, h->DT4, D, B, G / 2, h->s4, h->T4, h->P4pad, h->p4, rp ? &h->R4pad : nullptr, s));
+  // ---- SFP (reference dino.py:143-152,208-224; stages nohup.out:565-596; 4-level form clip.py:155-166) ----
   {
-    GemmParams p = gp_base(h->DT, D, h->convt, B * G2);
-    p.Ohi = h->CT.hi; p.Olo = h->CT.lo; p.G = G; p.Cout = D / 2;
-    KCHECK(h, gemm(h, p, EPI_CONVT, A_ROWMAJOR, s));
+    int li = 0;
+    if (h->nlev == 4) {                                    // scale 4: ConvT . LN . GELU . ConvT
+      KCHECK(h, convt_up(h, h->DT, D, B, G, h->convt4a, h->CT4a, s));
+      KCHECK(h, launch_ln_gelu_split(h->CT4a.hi, h->CT4a.lo, B * 4 * G2, D / 2, h->up_ln_g, h->up_ln_b, 1e-6f, s));
+      KCHECK(h, convt_up(h, h->CT4a, D / 2, B, 2 * G, h->convt4b, h->CT4b, s));
+      KCHECK(h, sfp_branch(h, h->CT4b, D / 4, B, h->lv[li++], s));
+    }
+    KCHECK(h, convt_up(h, h->DT, D, B, G, h->convt, h->CT, s));
+    KCHECK(h, sfp_branch(h, h->CT, D / 2, B, h->lv[li++], s));
+    KCHECK(h, sfp_branch(h, h->DT, D, B, h->lv[li++], s));
+    KCHECK(h, launch_maxpool2(h->DT.hi, h->DT.lo, B, G, D, h->DT4.hi, h->DT4.lo, s));
+    KCHECK(h, sfp_branch(h, h->DT4, D, B, h->lv[li++], s));
   }
-  KCHECK(h, sfp_branch(h, h->CT, D / 2, B, 2 * G, h->s2, h->T2, h->P2pad, h->p2, rp ? &h->R2pad : nullptr, s));
   const int C = h->C;
-  if (p2) HCHECK(h, hipMemcpyAsync(p2, h->p2, (size_t)B * 4 * G2 * C * 4, hipMemcpyDeviceToDevice, s));
-  if (p3) HCHECK(h, hipMemcpyAsync(p3, h->p3, (size_t)B * G2 * C * 4, hipMemcpyDeviceToDevice, s));
-  if (p4) HCHECK(h, hipMemcpyAsync(p4, h->p4, (size_t)B * (G / 2) * (G / 2) * C * 4, hipMemcpyDeviceToDevice, s));
+  float* outs[3] = {p2, p3, p4};
+  for (int l = 0; l < 3; ++l)
+    if (outs[l]) HCHECK(h, hipMemcpyAsync(outs[l], h->lv[l].p, (size_t)B * h->lv[l].side * h->lv[l].side * C * 4, hipMemcpyDeviceToDevice, s));
+  return OVM_OK;
+}
+
+int ovm_backbone_num_levels(const OvmHandle* h) { return h ? h->nlev : OVM_ERR_INVALID; }
+
+int ovm_backbone_level(const OvmHandle* h, int32_t level, const float** data, int32_t* side, float* stride) {
+  if (!h || level < 0 || level >= h->nlev) return OVM_ERR_INVALID;
+  if (data) *data = h->lv[level].p;
+  if (side) *side = h->lv[level].side;
+  if (stride) *stride = h->lv[level].stride;
   return OVM_OK;
 }
 
 static void roi_params(OvmHandle* h, RoiParams* rp) {
   memset(rp, 0, sizeof(*rp));
-  const int G = h->G;
-  rp->feat[0] = h->p2; rp->fh[0] = rp->fw[0] = 2 * G; rp->scale[0] = 1.0f / 7.0f;
-  rp->feat[1] = h->p3; rp->fh[1] = rp->fw[1] = G;     rp->scale[1] = 1.0f / 14.0f;
-  rp->feat[2] = h->p4; rp->fh[2] = rp->fw[2] = G / 2; rp->scale[2] = 1.0f / 28.0f;
-  rp->C = h->C; rp->nlevels = 3; rp->min_level = h->cfg.pooler_min_level; rp->max_level = h->cfg.pooler_max_level;
+  for (int l = 0; l < h->nlev; ++l) {
+    rp->feat[l] = h->lv[l].p; rp->fh[l] = rp->fw[l] = h->lv[l].side; rp->scale[l] = 1.0f / h->lv[l].stride;
+  }
+  rp->C = h->C; rp->nlevels = h->nlev; rp->min_level = h->cfg.pooler_min_level; rp->max_level = h->cfg.pooler_max_level;
   rp->out = h->cfg.pooler_res;
 }
 
@@ -711,15 +890,17 @@ int ovm_rpn_box_forward(OvmHandle* h, const OvmImage* images, int32_t B, float* 
   fill_meta(h, images, B);
   HCHECK(h, hipMemcpyAsync(h->d_meta, h->h_meta, sizeof(ImageMeta) * B, hipMemcpyHostToDevice, s));
   Det2dModel m; memset(&m, 0, sizeof(m));
-  m.npass = h->npass; m.B = B; m.G = h->G; m.C = h->C; m.F = h->cfg.fc_dim; m.roiK = h->roiK;
+  m.npass = h->npass; m.B = B; m.C = h->C; m.F = h->cfg.fc_dim; m.roiK = h->roiK;
   m.num_classes = h->cfg.num_classes;
-  m.rpad[0] = {h->R2pad.hi, h->R2pad.lo}; m.rpad[1] = {h->R3pad.hi, h->R3pad.lo}; m.rpad[2] = {h->R4pad.hi, h->R4pad.lo};
+  m.nlev = h->nlev;
+  for (int l = 0; l < h->nlev; ++l) { m.rpad[l] = {h->lv[l].rpad.hi, h->lv[l].rpad.lo}; m.stride[l] = h->lv[l].stride; }
   m.rpn_conv_hi = h->rpn_conv.w.hi; m.rpn_conv_lo = h->rpn_conv.w.lo; m.rpn_conv_bias = h->rpn_conv.bias;
   m.rpn_out_hi = h->rpn_out.w.hi; m.rpn_out_lo = h->rpn_out.w.lo; m.rpn_out_bias = h->rpn_out.bias;
   m.fc1_hi = h->box_fc1.w.hi; m.fc1_lo = h->box_fc1.w.lo; m.fc1_bias = h->box_fc1.bias;
   m.fc2_hi = h->box_fc2.w.hi; m.fc2_lo = h->box_fc2.w.lo; m.fc2_bias = h->box_fc2.bias;
   m.out_hi = h->box_out.w.hi; m.out_lo = h->box_out.w.lo; m.out_bias = h->box_out.bias;
-  for (int i = 0; i < 3; ++i) { m.anchor_sizes[i] = h->cfg.anchor_sizes[i]; m.anchor_ratios[i] = h->cfg.anchor_ratios[i]; }
+  for (int i = 0; i < kMaxLevels; ++i) m.anchor_sizes[i] = h->cfg.anchor_sizes[i];
+  for (int i = 0; i < 3; ++i) m.anchor_ratios[i] = h->cfg.anchor_ratios[i];
   m.pre_topk = h->cfg.rpn_pre_topk; m.post_topk = h->cfg.rpn_post_topk; m.rpn_nms = h->cfg.rpn_nms_thresh;
   m.score_thresh = h->cfg.score_thresh; m.nms_thresh = h->cfg.nms_thresh; m.topk = h->cfg.detections_per_image;
   m.meta = h->d_meta;
@@ -847,9 +1028,10 @@ int64_t ovm_debug_copy(OvmHandle* h, const char* name, float* dst, int64_t capac
   const float* src = nullptr; int64_t n = 0;
   const std::string k(name);
   if (k == "tokens") { src = h->X; n = (int64_t)B * h->T * h->D; }
-  else if (k == "p2") { src = h->p2; n = (int64_t)B * 4 * G * G * C; }
-  else if (k == "p3") { src = h->p3; n = (int64_t)B * G * G * C; }
-  else if (k == "p4") { src = h->p4; n = (int64_t)B * (G / 2) * (G / 2) * C; }
+  else if (k.size() == 2 && k[0] == 'p' && k[1] >= '2' && k[1] < '2' + h->nlev) {
+    const FpnLevel& f = h->lv[k[1] - '2'];
+    src = f.p; n = (int64_t)B * f.side * f.side * C;
+  }
   else { h->err = "unknown debug tensor"; return OVM_ERR_INVALID; }
   if (n > capacity) { h->err = "debug copy capacity too small"; return OVM_ERR_CAPACITY; }
   if (hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return OVM_ERR_HIP;

@@ -148,49 +148,50 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const int* __restrict__ gr
 // RPN
 // ------------------------------------------------------------------------------------------------
 struct RpnGeom {
-  int HW[3], Wl[3], A_off[4];     // anchors per level prefix (A = 3 per cell)
-  float base[3][3][4];            // [level][ratio][xyxy] cell anchors (computed in double on the host)
-  float stride[3];
+  int nlev;
+  int HW[kMaxLevels], Wl[kMaxLevels], A_off[kMaxLevels + 1];     // anchors per level prefix (A = 3 per cell)
+  float base[kMaxLevels][3][4];   // [level][ratio][xyxy] cell anchors (computed in double on the host)
+  float stride[kMaxLevels];
+  const float* o[kMaxLevels];     // per level [B*HW][16]: 3 objectness logits + 12 deltas
 };
 
 // key = level (2 bits @58) | ~ord(score) (32 bits @24) | local anchor index (24 bits)
-__global__ void rpn_keys_kernel(const float* __restrict__ o0, const float* __restrict__ o1, const float* __restrict__ o2,
-                                RpnGeom gm, int N, unsigned long long* __restrict__ keys) {
+__global__ void rpn_keys_kernel(RpnGeom gm, int N, unsigned long long* __restrict__ keys) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.y;
   if (g >= N) return;
   unsigned long long key = kInvalidKey;
-  if (g < gm.A_off[3]) {
-    const int l = (g >= gm.A_off[2]) ? 2 : ((g >= gm.A_off[1]) ? 1 : 0);
+  if (g < gm.A_off[gm.nlev]) {
+    int l = 0;
+    for (int q = 1; q < gm.nlev; ++q) l = (g >= gm.A_off[q]) ? q : l;
     const int local = g - gm.A_off[l];
     const int cell = local / 3, a = local - cell * 3;
-    const float* o = (l == 0) ? o0 : ((l == 1) ? o1 : o2);
+    const float* o = gm.o[l];
     const float sc = o[((size_t)b * gm.HW[l] + cell) * 16 + a];
     key = ((unsigned long long)l << 58) | ((unsigned long long)(~ord32(sc)) << 24) | (unsigned long long)local;
   }
   keys[(size_t)b * N + g] = key;
 }
 
-__global__ void rpn_decode_kernel(const unsigned long long* __restrict__ keys, const float* __restrict__ o0,
-                                  const float* __restrict__ o1, const float* __restrict__ o2, RpnGeom gm, int N, int pre_topk,
+__global__ void rpn_decode_kernel(const unsigned long long* __restrict__ keys, RpnGeom gm, int N, int pre_topk,
                                   const ImageMeta* __restrict__ meta, float scale_clamp, float* __restrict__ cbox,
                                   float* __restrict__ cscore, int* __restrict__ cgroup, int* __restrict__ gstart,
                                   int* __restrict__ gend) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.y;
-  const int NS = 3 * pre_topk;
+  const int NS = gm.nlev * pre_topk;
   if (s >= NS) return;
   const int l = s / pre_topk, i = s - l * pre_topk;
   const int A_l = gm.A_off[l + 1] - gm.A_off[l];
   const int k_l = A_l < pre_topk ? A_l : pre_topk;
-  if (i == 0) { gstart[b * 3 + l] = l * pre_topk; gend[b * 3 + l] = l * pre_topk + k_l; }
+  if (i == 0) { gstart[b * gm.nlev + l] = l * pre_topk; gend[b * gm.nlev + l] = l * pre_topk + k_l; }
   const size_t so = (size_t)b * NS + s;
   if (i >= k_l) { cgroup[so] = -1; cscore[so] = 0.f; cbox[so * 4] = cbox[so * 4 + 1] = cbox[so * 4 + 2] = cbox[so * 4 + 3] = 0.f; return; }
   const unsigned long long key = keys[(size_t)b * N + gm.A_off[l] + i];
   const int local = (int)(key & kIdMask);
   const int cell = local / 3, a = local - cell * 3;
   const int y = cell / gm.Wl[l], x = cell - y * gm.Wl[l];
-  const float* o = ((l == 0) ? o0 : ((l == 1) ? o1 : o2)) + ((size_t)b * gm.HW[l] + cell) * 16;
+  const float* o = gm.o[l] + ((size_t)b * gm.HW[l] + cell) * 16;
   const float sc = o[a];
   const float sx = (float)x * gm.stride[l], sy = (float)y * gm.stride[l];
   const float ax1 = sx + gm.base[l][a][0], ay1 = sy + gm.base[l][a][1];
@@ -369,36 +370,37 @@ int dmalloc(Tp** p, size_t n, std::vector<void*>* allocs) {
 
 }  // namespace
 
-int det2d_alloc(Det2dWorkspace* w, int B, int G, int C, int num_classes, int maxR, int pre_topk, int post_topk, int topk,
-                std::vector<void*>* allocs) {
+int det2d_alloc(Det2dWorkspace* w, int B, int nlev, const int* sides, int C, int num_classes, int maxR, int pre_topk, int post_topk,
+                int topk, std::vector<void*>* allocs) {
   memset(w, 0, sizeof(*w));
-  w->maxB = B; w->G = G; w->C = C; w->num_classes = num_classes; w->pre_topk = pre_topk; w->topk = topk;
+  if (nlev < 1 || nlev > kMaxLevels) return OVM_ERR_INVALID;
+  w->maxB = B; w->nlev = nlev; w->C = C; w->num_classes = num_classes; w->pre_topk = pre_topk; w->topk = topk;
   w->R = post_topk < maxR ? post_topk : maxR;
-  const int Wl[3] = {2 * G, G, G / 2};
   int A = 0;
-  for (int l = 0; l < 3; ++l) { w->Wl[l] = Wl[l]; w->HW[l] = Wl[l] * Wl[l]; A += w->HW[l] * 3; }
+  for (int l = 0; l < nlev; ++l) { w->Wl[l] = sides[l]; w->HW[l] = sides[l] * sides[l]; A += w->HW[l] * 3; }
+  if (A >= (1 << 24)) return OVM_ERR_CAPACITY;                          // the sort key carries a 24-bit local anchor index
   w->A_tot = A;
   w->Nrpn = pow2_at_least(A);
   w->Ncand = pow2_at_least(w->R * num_classes);
-  w->Nmerge = pow2_at_least(3 * pre_topk);
+  w->Nmerge = pow2_at_least(nlev * pre_topk);
   if (pre_topk > 1024 || w->R > 1024 || topk > 1024 || num_classes > 63 || (size_t)w->R * num_classes >= (1u << 24)) return OVM_ERR_CAPACITY;
   int r;
-  for (int l = 0; l < 3; ++l) {
+  for (int l = 0; l < nlev; ++l) {
     if ((r = dmalloc(&w->rpn_t[l].hi, (size_t)B * w->HW[l] * C, allocs))) return r;
     if ((r = dmalloc(&w->rpn_t[l].lo, (size_t)B * w->HW[l] * C, allocs))) return r;
     if ((r = dmalloc(&w->rpn_o[l], (size_t)B * w->HW[l] * 16, allocs))) return r;
   }
   const size_t nk = (size_t)B * (w->Nrpn > w->Ncand ? w->Nrpn : w->Ncand);
   if ((r = dmalloc(&w->keys, nk, allocs))) return r;
-  const size_t NS = (size_t)B * 3 * pre_topk;
+  const size_t NS = (size_t)B * nlev * pre_topk;
   if ((r = dmalloc(&w->cbox, NS * 4, allocs))) return r;
   if ((r = dmalloc(&w->cscore, NS, allocs))) return r;
   if ((r = dmalloc(&w->cgroup, NS, allocs))) return r;
   if ((r = dmalloc(&w->ckeep, NS, allocs))) return r;
-  const int ng = num_classes > 3 ? num_classes : 3;
+  const int ng = num_classes > nlev ? num_classes : nlev;
   if ((r = dmalloc(&w->gstart, (size_t)B * ng, allocs))) return r;
   if ((r = dmalloc(&w->gend, (size_t)B * ng, allocs))) return r;
-  const size_t nmask = (size_t)B * (w->Ncand > 3 * pre_topk ? w->Ncand : 3 * pre_topk) * 16;
+  const size_t nmask = (size_t)B * (w->Ncand > nlev * pre_topk ? w->Ncand : nlev * pre_topk) * 16;
   if ((r = dmalloc(&w->mask, nmask, allocs))) return r;
   if ((r = dmalloc(&w->mkeys, (size_t)B * w->Nmerge, allocs))) return r;
   const size_t BR = (size_t)B * w->R;
@@ -419,11 +421,14 @@ int det2d_forward(const Det2dModel& m, Det2dWorkspace& w, float* boxes, float* s
   const int B = m.B, C = m.C, K = m.num_classes;
   if (B > w.maxB || m.pre_topk != w.pre_topk || K != w.num_classes) return OVM_ERR_CAPACITY;
   const float scale_clamp = (float)std::log(1000.0 / 16.0);
+  const int nlev = m.nlev;
+  if (nlev != w.nlev) return OVM_ERR_CAPACITY;
   RpnGeom gm; memset(&gm, 0, sizeof(gm));
+  gm.nlev = nlev;
   gm.A_off[0] = 0;
-  for (int l = 0; l < 3; ++l) {
+  for (int l = 0; l < nlev; ++l) {
     gm.HW[l] = w.HW[l]; gm.Wl[l] = w.Wl[l]; gm.A_off[l + 1] = gm.A_off[l] + w.HW[l] * 3;
-    gm.stride[l] = 7.0f * (float)(1 << l);
+    gm.stride[l] = m.stride[l]; gm.o[l] = w.rpn_o[l];
     for (int a = 0; a < 3; ++a) {                         // DefaultAnchorGenerator.generate_cell_anchors
       const double area = (double)m.anchor_sizes[l] * (double)m.anchor_sizes[l];
       const double ww = std::sqrt(area / (double)m.anchor_ratios[a]);
@@ -433,7 +438,7 @@ int det2d_forward(const Det2dModel& m, Det2dWorkspace& w, float* boxes, float* s
     }
   }
   // ---- RPN head: conv3x3+bias+ReLU (implicit GEMM over the zero-bordered fp16 pyramid), then the 1x1s ----
-  for (int l = 0; l < 3; ++l) {
+  for (int l = 0; l < nlev; ++l) {
     const int Hs = w.Wl[l], M = B * w.HW[l];
     GemmParams p; memset(&p, 0, sizeof(p));
     p.Ahi = m.rpad[l].hi; p.Alo = m.rpad[l].lo; p.Whi = m.rpn_conv_hi; p.Wlo = m.rpn_conv_lo;
@@ -448,16 +453,16 @@ int det2d_forward(const Det2dModel& m, Det2dWorkspace& w, float* boxes, float* s
     if (r) return r;
   }
   // ---- per-level top-k (sort of (level, score, index) keys), decode, clip ----
-  const int N = w.Nrpn, NS = 3 * m.pre_topk;
-  hipLaunchKernelGGL(rpn_keys_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, w.rpn_o[0], w.rpn_o[1], w.rpn_o[2], gm, N, w.keys);
+  const int N = w.Nrpn, NS = nlev * m.pre_topk;
+  hipLaunchKernelGGL(rpn_keys_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, gm, N, w.keys);
   int r = sort_keys(w.keys, N, B, s);
   if (r) return r;
-  hipLaunchKernelGGL(rpn_decode_kernel, dim3((NS + 255) / 256, B), dim3(256), 0, s, w.keys, w.rpn_o[0], w.rpn_o[1], w.rpn_o[2], gm, N,
+  hipLaunchKernelGGL(rpn_decode_kernel, dim3((NS + 255) / 256, B), dim3(256), 0, s, w.keys, gm, N,
                      m.pre_topk, m.meta, scale_clamp, w.cbox, w.cscore, w.cgroup, w.gstart, w.gend);
   // ---- per-level NMS, merge by score, keep post_topk ----
-  hipLaunchKernelGGL(nms_mask_kernel, dim3((NS * 16 + 127) / 128, B), dim3(128), 0, s, w.cbox, w.cgroup, w.gstart, w.gend, 3, NS, 16,
+  hipLaunchKernelGGL(nms_mask_kernel, dim3((NS * 16 + 127) / 128, B), dim3(128), 0, s, w.cbox, w.cgroup, w.gstart, w.gend, nlev, NS, 16,
                      m.rpn_nms, w.mask);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(3, B), dim3(64), 0, s, w.cgroup, w.gstart, w.gend, 3, NS, 16, w.mask, w.ckeep);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(nlev, B), dim3(64), 0, s, w.cgroup, w.gstart, w.gend, nlev, NS, 16, w.mask, w.ckeep);
   hipLaunchKernelGGL(rpn_merge_keys_kernel, dim3((w.Nmerge + 255) / 256, B), dim3(256), 0, s, w.cscore, w.ckeep, NS, w.Nmerge, w.mkeys);
   r = sort_keys(w.mkeys, w.Nmerge, B, s);
   if (r) return r;

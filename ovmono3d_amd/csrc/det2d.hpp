@@ -13,18 +13,18 @@ namespace ovm {
 struct SplitPtr { half_t* hi; half_t* lo; };
 
 struct Det2dWorkspace {
-  int maxB, G, C, num_classes, R, pre_topk, topk;
-  int HW[3], Wl[3];                    // per level pixels / width
+  int maxB, nlev, C, num_classes, R, pre_topk, topk;
+  int HW[kMaxLevels], Wl[kMaxLevels];  // per level pixels / width
   int A_tot;                           // total anchors per image
   int Nrpn;                            // pow2 >= A_tot (sort length)
   int Ncand;                           // pow2 >= R * num_classes
-  int Nmerge;                          // pow2 >= 3 * pre_topk
-  SplitPtr rpn_t[3];                   // conv3x3+ReLU output per level, fp16 split [B*HW][C]
-  float* rpn_o[3];                     // [B*HW][16] fp32: 3 objectness logits + 12 deltas
+  int Nmerge;                          // pow2 >= nlev * pre_topk
+  SplitPtr rpn_t[kMaxLevels];          // conv3x3+ReLU output per level, fp16 split [B*HW][C]
+  float* rpn_o[kMaxLevels];            // [B*HW][16] fp32: 3 objectness logits + 12 deltas
   unsigned long long* keys;            // [B][max(Nrpn, Ncand)]
   // RPN candidates, slot = l*pre_topk + i
-  float* cbox; float* cscore; int* cgroup; int* cseg; int* ckeep;     // [B][3*pre_topk](x4)
-  int* gstart; int* gend;              // [B][max(3, num_classes)]
+  float* cbox; float* cscore; int* cgroup; int* cseg; int* ckeep;     // [B][nlev*pre_topk](x4)
+  int* gstart; int* gend;              // [B][max(nlev, num_classes)]
   unsigned long long* mask;            // [B][Nmask][16]
   unsigned long long* mkeys;           // [B][Nmerge]
   float* prop_boxes; float* prop_scores; int* prop_bidx; int* prop_count;   // [B][R]
@@ -35,14 +35,14 @@ struct Det2dWorkspace {
 };
 
 struct Det2dModel {
-  int npass, B, G, C, F, roiK, num_classes;
-  SplitPtr rpad[3];
+  int npass, B, nlev, C, F, roiK, num_classes;
+  SplitPtr rpad[kMaxLevels]; float stride[kMaxLevels];
   const half_t *rpn_conv_hi, *rpn_conv_lo; const float* rpn_conv_bias;
   const half_t *rpn_out_hi, *rpn_out_lo; const float* rpn_out_bias;
   const half_t *fc1_hi, *fc1_lo; const float* fc1_bias;
   const half_t *fc2_hi, *fc2_lo; const float* fc2_bias;
   const half_t *out_hi, *out_lo; const float* out_bias;
-  float anchor_sizes[3], anchor_ratios[3];
+  float anchor_sizes[kMaxLevels], anchor_ratios[3];
   int pre_topk, post_topk; float rpn_nms;
   float score_thresh, nms_thresh; int topk;
   const ImageMeta* meta;
@@ -50,7 +50,7 @@ struct Det2dModel {
   SplitPtr RF, H1, H2; float* HO;
 };
 
-int det2d_alloc(Det2dWorkspace* w, int B, int G, int C, int num_classes, int maxR, int pre_topk, int post_topk, int topk,
+int det2d_alloc(Det2dWorkspace* w, int B, int nlev, const int* sides, int C, int num_classes, int maxR, int pre_topk, int post_topk, int topk,
                 std::vector<void*>* allocs);
 int det2d_forward(const Det2dModel& m, Det2dWorkspace& w, float* boxes, float* scores, int* classes, int* image_idx,
                   float* scores_full, int* out_counts, hipStream_t s);

@@ -8,36 +8,39 @@ namespace ovm {
 // Patch gather: u8 image (arbitrary C/H/W strides, so CHW dict tensors and native NHWC both work)
 // -> normalised fp16 split rows A[b*G2 + p][k], k = (py*14 + px)*3 + c, zero beyond the image
 // (ImageList pad value 0 is applied AFTER normalisation) and zero in the K padding columns.
-// One thread per (patch, py): 14 px * 3 c = 42 outputs (84 contiguous bytes per part).
-// Follows detectron2 preprocess_image as called at reference rcnn3d.py:88 + dinov2 PatchEmbed.
+// One thread per (patch, py): P px * 3 c outputs (P = 14: 84 contiguous bytes per part; P = 16: 96).
+// Follows detectron2 preprocess_image as called at reference rcnn3d.py:88 + the ViT's patch conv
+// (dinov2 PatchEmbed 14x14/14; open_clip conv1 16x16/16, reference clip.py:66).
 // ---------------------------------------------------------------------------------------------
+template <int P>
 __global__ void patch_gather_kernel(const ImageDesc* __restrict__ imgs, int B, int G, int Kpad,
                                     float m0, float m1, float m2, float s0, float s1, float s2,
                                     half_t* __restrict__ Ahi, half_t* __restrict__ Alo) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int G2 = G * G;
-  const int total = B * G2 * 16;                    // 14 py rows + 2 "rows" that zero the K padding
+  constexpr int RPP = (P == 14) ? 16 : P;           // threads per patch; P = 14: 14 py rows + 2 "rows" that zero the K padding
+  const int total = B * G2 * RPP;
   if (idx >= total) return;
-  const int py = idx & 15;
-  const int pid = idx >> 4;
+  const int py = idx % RPP;
+  const int pid = idx / RPP;
   const int b = pid / G2, p = pid - b * G2;
   const int gy = p / G, gx = p - gy * G;
   half_t* oh = Ahi + (size_t)pid * Kpad;
   half_t* ol = Alo ? Alo + (size_t)pid * Kpad : nullptr;
-  if (py >= 14) {                                   // K padding: columns 588..Kpad-1, split over 2 threads
-    const int kpad0 = 588, n = Kpad - kpad0;
+  if (py >= P) {                                    // K padding: columns 3 P^2..Kpad-1, split over 2 threads
+    const int kpad0 = 3 * P * P, n = Kpad - kpad0;
     const int half_n = (n + 1) / 2;
-    const int beg = kpad0 + (py - 14) * half_n;
+    const int beg = kpad0 + (py - P) * half_n;
     const int end = min(Kpad, beg + half_n);
     for (int k = beg; k < end; ++k) { oh[k] = (half_t)0.f; if (ol) ol[k] = (half_t)0.f; }
     return;
   }
   const ImageDesc d = imgs[b];
-  const int y = gy * 14 + py;
+  const int y = gy * P + py;
   const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
-  const int k0 = py * 42;
-  for (int px = 0; px < 14; ++px) {
-    const int x = gx * 14 + px;
+  const int k0 = py * 3 * P;
+  for (int px = 0; px < P; ++px) {
+    const int x = gx * P + px;
     const bool in = (y < d.H) && (x < d.W);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -50,11 +53,19 @@ __global__ void patch_gather_kernel(const ImageDesc* __restrict__ imgs, int B, i
   }
 }
 
-int launch_patch_gather(const ImageDesc* d_imgs, int B, int G, int Kpad, const float* mean, const float* stdv,
+int launch_patch_gather(const ImageDesc* d_imgs, int B, int G, int patch, int Kpad, const float* mean, const float* stdv,
                         half_t* Ahi, half_t* Alo, hipStream_t s) {
-  const int total = B * G * G * 16;
-  hipLaunchKernelGGL(patch_gather_kernel, dim3((total + 255) / 256), dim3(256), 0, s, d_imgs, B, G, Kpad,
-                     mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2], Ahi, Alo);
+  if (patch == 14) {
+    const int total = B * G * G * 16;
+    hipLaunchKernelGGL(patch_gather_kernel<14>, dim3((total + 255) / 256), dim3(256), 0, s, d_imgs, B, G, Kpad,
+                       mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2], Ahi, Alo);
+  } else if (patch == 16 && Kpad == 768) {
+    const int total = B * G * G * 16;
+    hipLaunchKernelGGL(patch_gather_kernel<16>, dim3((total + 255) / 256), dim3(256), 0, s, d_imgs, B, G, Kpad,
+                       mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2], Ahi, Alo);
+  } else {
+    return OVM_ERR_INVALID;
+  }
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 
@@ -137,6 +148,72 @@ int launch_ln_rows(const float* X, int ldx, int M, int D, const float* gamma, co
   if (D <= 256) hipLaunchKernelGGL(ln_rows_kernel<1>, grid, block, 0, s, X, ldx, M, D, gamma, beta, eps, o);
   else if (D <= 1024) hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, X, ldx, M, D, gamma, beta, eps, o);
   else hipLaunchKernelGGL(ln_rows_kernel<8>, grid, block, 0, s, X, ldx, M, D, gamma, beta, eps, o);
+  return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Channel LayerNorm + erf-GELU, in place, on fp16 split rows [M][D] (value = hi + lo; lo null in one-pass mode): the
+// middle of the scale-4 stage of the simple feature pyramid, ConvT -> LN -> GELU -> ConvT (detectron2 SimpleFeaturePyramid,
+// built at reference clip.py:155-166). One wave per row, D <= 1024.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_gelu_split_kernel(half_t* __restrict__ Hi, half_t* __restrict__ Lo, int M, int D,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const int nv = D >> 2;
+  half_t* hi = Hi + (size_t)row * D;
+  half_t* lo = Lo ? Lo + (size_t)row * D : nullptr;
+  f32x4 v[4];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = lane + i * 64;
+    if (j < nv) {
+      const half4 h = *(const half4*)(hi + j * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[i][r] = (float)h[r];
+      if (lo) {
+        const half4 l = *(const half4*)(lo + j * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[i][r] += (float)l[r];
+      }
+      sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = lane + i * 64;
+    if (j < nv) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float d = v[i][r] - mean; sq += d * d; }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = lane + i * 64;
+    if (j < nv) {
+      const f32x4 g = ((const f32x4*)gamma)[j];
+      const f32x4 bt = ((const f32x4*)beta)[j];
+      half4 h, l;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float y = gelu_erf((v[i][r] - mean) * rstd * g[r] + bt[r]);
+        half_t hh, ll; split_f16(y, hh, ll); h[r] = hh; l[r] = ll;
+      }
+      *(half4*)(hi + j * 4) = h;
+      if (lo) *(half4*)(lo + j * 4) = l;
+    }
+  }
+}
+
+int launch_ln_gelu_split(half_t* hi, half_t* lo, int M, int D, const float* gamma, const float* beta, float eps, hipStream_t s) {
+  if (D % 4 != 0 || D > 1024) return OVM_ERR_SHAPE;
+  hipLaunchKernelGGL(ln_gelu_split_kernel, dim3((M + 3) / 4), dim3(256), 0, s, hi, lo, M, D, gamma, beta, eps);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 

@@ -49,7 +49,7 @@ struct GemmParams {
   float* C; int ldc;                              // EPI_STORE: fp32 out (or null)
   half_t* Ohi; half_t* Olo; int ldo;              // EPI_STORE / EPI_GELU / EPI_CONVT: fp16 split out (or null)
   int o_il;                                       // EPI_GELU: Ohi / Olo form an interleaved image (Olo = Ohi + 32, ldo = 2 N)
-  int relu;                                       // EPI_STORE activation: 0 none, 1 ReLU, 2 GELU(erf)
+  int relu;                                       // EPI_STORE activation: 0 none, 1 ReLU, 2 GELU(erf); EPI_GELU: 3 = QuickGELU, else erf
   const float* R; int ldr;                        // EPI_STORE: optional fp32 residual added after the activation
   // EPI_STORE with padded-NHWC destination for Ohi/Olo (conv input): if padH>0, row m=(b,y,x) goes to
   // ((b*(padH+2) + y+1)*(padW+2) + x+1)
@@ -120,6 +120,8 @@ __device__ __forceinline__ uint32_t a_k_off(const GemmParams& p, int k0) {
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// open_clip QuickGELU (the activation of the OpenAI CLIP weights): x * sigmoid(1.702 x)
+__device__ __forceinline__ float gelu_quick(float x) { return x / (1.0f + expf(-1.702f * x)); }
 
 template <int EPI>
 __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32x4 v) {
@@ -147,7 +149,10 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32
   } else if (EPI == EPI_GELU) {
     half4 h, l;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { half_t hh, ll; split_f16(gelu_erf(v[r] + b4[r]), hh, ll); h[r] = hh; l[r] = ll; }
+    for (int r = 0; r < 4; ++r) {
+      const float z = v[r] + b4[r];
+      half_t hh, ll; split_f16(p.relu == 3 ? gelu_quick(z) : gelu_erf(z), hh, ll); h[r] = hh; l[r] = ll;
+    }
     const size_t o = (size_t)m * p.ldo + (p.o_il ? il_col(n) : n);
     *(half4*)(p.Ohi + o) = h;
     if (p.Olo) *(half4*)(p.Olo + o) = l;

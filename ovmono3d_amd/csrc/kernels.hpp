@@ -29,8 +29,10 @@ struct AttnParams {
   unsigned long long* stamps;                        // diagnostic build of the two-wave-group kernel: s_memtime per barrier, [8 waves][128]
 };
 
+constexpr int kMaxLevels = 4;   // pyramid levels: 3 (scales 2, 1, 0.5 - the DINOv2 tower) or 4 (4, 2, 1, 0.5 - CLIP / ViTDet style)
+
 struct RoiParams {
-  const float* feat[3]; int fh[3], fw[3]; float scale[3];   // NHWC fp32 levels
+  const float* feat[kMaxLevels]; int fh[kMaxLevels], fw[kMaxLevels]; float scale[kMaxLevels];   // NHWC fp32 levels
   int C, nlevels, min_level, max_level, out;                 // out = pooled resolution (7)
   const float* boxes;                                        // [n][4] xyxy network res
   const int* batch_idx;                                      // [n]
@@ -62,8 +64,9 @@ struct CubeDecodeParams {
   int* keep;                       // [n] 1 if the post-processed 2D box is non-empty
 };
 
-int launch_patch_gather(const ImageDesc* d_imgs, int B, int G, int Kpad, const float* mean, const float* stdv,
+int launch_patch_gather(const ImageDesc* d_imgs, int B, int G, int patch, int Kpad, const float* mean, const float* stdv,
                         half_t* Ahi, half_t* Alo, hipStream_t s);
+int launch_ln_gelu_split(half_t* hi, half_t* lo, int M, int D, const float* gamma, const float* beta, float eps, hipStream_t s);
 int launch_cls_init(float* X, const float* cls, const float* pos, int B, int T, int D, hipStream_t s);
 int launch_ln_rows(const float* X, int ldx, int M, int D, const float* gamma, const float* beta, float eps,
                    const LnOut& o, hipStream_t s);

@@ -90,7 +90,10 @@ class DatasetMapper3D:
         assert not is_train, "training is out of scope"
         self.image_format = cfg.INPUT.FORMAT
         self.resize = ResizeShortestEdge(cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
-        self.use_depth = bool(cfg.MODEL.DINO.USE_DEPTH_FUSION) and depth_dir is not None
+        # only the DINOv2 tower has the depth-fusion conv; the other backbones take no depth (backbone/clip.py), so no depth
+        # prompt is loaded for them even when a folder is given
+        self.use_depth = (bool(cfg.MODEL.DINO.USE_DEPTH_FUSION) and cfg.MODEL.BACKBONE.NAME == "build_dino_backbone"
+                          and depth_dir is not None)
         self.depth_dir = depth_dir
         # device-side ResizeShortestEdge (bit-identical to the Pillow path; gpu_resize.py) when a HIP device is present
         self.gpu_resize = None

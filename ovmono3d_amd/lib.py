@@ -27,11 +27,15 @@ class OvmConfig(C.Structure):
         ("num_classes", C.c_int32), ("fc_dim", C.c_int32), ("pooler_res", C.c_int32),
         ("pooler_min_level", C.c_int32), ("pooler_max_level", C.c_int32),
         ("virtual_focal", C.c_float),
-        ("anchor_sizes", C.c_float * 3), ("anchor_ratios", C.c_float * 3),
+        ("anchor_sizes", C.c_float * 4), ("anchor_ratios", C.c_float * 3),
         ("rpn_pre_topk", C.c_int32), ("rpn_post_topk", C.c_int32), ("rpn_nms_thresh", C.c_float),
         ("score_thresh", C.c_float), ("nms_thresh", C.c_float), ("detections_per_image", C.c_int32),
         ("precision", C.c_int32), ("max_batch", C.c_int32), ("max_rois", C.c_int32),
+        ("tower", C.c_int32),
     ]
+
+
+OVM_TOWER_DINOV2, OVM_TOWER_CLIP = 0, 1
 
 
 class OvmTensor(C.Structure):
@@ -56,8 +60,9 @@ class OvmGdinoConfig(C.Structure):
 
 
 EXPORTS = [
-    "ovm_create", "ovm_destroy", "ovm_last_error", "ovm_version", "ovm_backbone_forward", "ovm_cube_forward",
-    "ovm_rpn_box_forward", "ovm_gather_records", "ovm_gather_counts", "ovm_host_interp_pos_embed", "ovm_host_shard_range",
+    "ovm_create", "ovm_destroy", "ovm_last_error", "ovm_version", "ovm_abi_sizeof", "ovm_backbone_forward", "ovm_cube_forward",
+    "ovm_rpn_box_forward", "ovm_gather_records", "ovm_gather_counts", "ovm_host_interp_pos_embed", "ovm_host_resize_pos_embed_aa", "ovm_host_shard_range",
+    "ovm_backbone_num_levels", "ovm_backbone_level",
     "ovm_op_split_f16", "ovm_op_interleave", "ovm_op_gemm", "ovm_op_layernorm", "ovm_op_attention", "ovm_op_roi_align",
     "ovm_op_cube_decode", "ovm_op_nms", "ovm_debug_copy", "ovm_set_corun", "ovm_profile_enable", "ovm_profile_read",
     "ovm_comm_unique_id", "ovm_comm_init", "ovm_comm_destroy", "ovm_tune_set", "ovm_gdino_postprocess", "ovm_box3d_iou", "ovm_host_pil_bilinear_coeffs", "ovm_resize_bilinear_u8",
@@ -87,12 +92,20 @@ def load() -> C.CDLL:
     lib.ovm_last_error.argtypes = [vp]
     lib.ovm_last_error.restype = C.c_char_p
     lib.ovm_version.restype = C.c_char_p
+    lib.ovm_abi_sizeof.argtypes = [C.c_char_p]
+    for name, mirror in (("OvmConfig", OvmConfig), ("OvmTensor", OvmTensor), ("OvmImage", OvmImage), ("OvmGdinoConfig", OvmGdinoConfig)):
+        if lib.ovm_abi_sizeof(name.encode()) != C.sizeof(mirror):
+            raise RuntimeError(f"{LIB_PATH}: sizeof({name}) = {lib.ovm_abi_sizeof(name.encode())} but the ctypes mirror has "
+                               f"{C.sizeof(mirror)} bytes - rebuild the library (ovmono3d_amd/csrc/build.sh) or update lib.py")
     lib.ovm_backbone_forward.argtypes = [vp, C.POINTER(OvmImage), i32, vp, i32, i32, vp, vp, vp, vp]
     lib.ovm_cube_forward.argtypes = [vp, C.POINTER(OvmImage), i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     lib.ovm_rpn_box_forward.argtypes = [vp, C.POINTER(OvmImage), i32, vp, vp, vp, vp, vp, vp, vp]
     lib.ovm_gather_records.argtypes = [vp, i32, i32, vp, i32, vp, C.POINTER(i32), vp]
     lib.ovm_gather_counts.argtypes = [vp, i32, i32, i32, C.POINTER(i32), vp]
     lib.ovm_host_interp_pos_embed.argtypes = [vp, i32, i32, i32, vp]
+    lib.ovm_host_resize_pos_embed_aa.argtypes = [vp, i32, i32, i32, vp]
+    lib.ovm_backbone_num_levels.argtypes = [vp]
+    lib.ovm_backbone_level.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(f32)]
     lib.ovm_host_shard_range.argtypes = [i64, i32, i32, C.POINTER(i64), C.POINTER(i64)]
     lib.ovm_op_split_f16.argtypes = [vp, i64, vp, vp, vp]
     lib.ovm_op_interleave.argtypes = [vp, vp, i64, i32, vp, vp]

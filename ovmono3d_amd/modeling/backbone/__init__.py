@@ -1,1 +1,2 @@
 from .dino import DINOBackbone, SimpleFeaturePyramidWithDepth, build_dino_backbone  # noqa: F401
+from .clip import CLIPBackbone, SimpleFeaturePyramid, build_clip_backbone  # noqa: F401

@@ -76,8 +76,8 @@ class SimpleFeaturePyramidWithDepth:
 
     def __init__(self, net: DINOBackbone, in_feature, out_channels, scale_factors, norm="LN", top_block=None,
                  square_pad=0, engine: Optional[Engine] = None, cfg=None):
-        if tuple(scale_factors) != (2.0, 1.0, 0.5) or norm != "LN" or top_block is not None:
-            raise NotImplementedError("native SFP: scale_factors (2.0, 1.0, 0.5), norm 'LN', no top block")
+        if tuple(scale_factors) not in ((2.0, 1.0, 0.5), (4.0, 2.0, 1.0, 0.5)) or norm != "LN" or top_block is not None:
+            raise NotImplementedError("native SFP: scale_factors (2, 1, 0.5) or (4, 2, 1, 0.5), norm 'LN', no top block")
         self.net = net
         self.in_feature = in_feature
         self.scale_factors = scale_factors
@@ -119,8 +119,7 @@ class SimpleFeaturePyramidWithDepth:
         feats = self.engine.backbone_forward(native, B, prompt_depth, export=self.export_features)
         if feats is not None:
             return feats
-        G = self.engine.G
-        return {k: FeatureRef(self.engine, k, B, g, self.engine.C) for k, g in (("p2", 2 * G), ("p3", G), ("p4", G // 2))}
+        return {k: FeatureRef(self.engine, k, B, g, self.engine.C) for k, g, _ in self.engine.levels}
 
     __call__ = forward
 

@@ -12,19 +12,35 @@ import numpy as np
 import torch
 
 from . import lib as _lib
-from .lib import OVM_REC_FLOATS, OvmConfig, OvmImage, check
-from .util.synth_weights import VIT_ARCH
+from .lib import OVM_REC_FLOATS, OVM_TOWER_CLIP, OVM_TOWER_DINOV2, OvmConfig, OvmImage, check
+from .util.synth_weights import CLIP_ARCH, VIT_ARCH
 
 
 def config_to_native(cfg) -> OvmConfig:
     """Reference config tree -> OvmConfig (keys cited in include/ovm3d.h)."""
-    name = cfg.MODEL.DINO.MODEL_NAME
-    if name not in VIT_ARCH:
-        raise ValueError(f"unsupported MODEL.DINO.MODEL_NAME {name!r} (known: {sorted(VIT_ARCH)})")
-    if cfg.MODEL.DINO.NAME != "dinov2":
-        raise ValueError("only MODEL.DINO.NAME == 'dinov2' is on this path")
-    if cfg.MODEL.DINO.OUTPUT != "dense" or cfg.MODEL.DINO.RETURN_MULTILAYER or cfg.MODEL.DINO.LAYER != -1:
-        raise ValueError("native path supports MODEL.DINO.OUTPUT 'dense', LAYER -1, single layer")
+    backbone = cfg.MODEL.BACKBONE.NAME
+    if backbone == "build_dino_backbone":
+        tower, patch = OVM_TOWER_DINOV2, 14
+        name = cfg.MODEL.DINO.MODEL_NAME
+        if name not in VIT_ARCH:
+            raise ValueError(f"unsupported MODEL.DINO.MODEL_NAME {name!r} (known: {sorted(VIT_ARCH)})")
+        if cfg.MODEL.DINO.NAME != "dinov2":
+            raise ValueError("only MODEL.DINO.NAME == 'dinov2' is on this path")
+        if cfg.MODEL.DINO.OUTPUT != "dense" or cfg.MODEL.DINO.RETURN_MULTILAYER or cfg.MODEL.DINO.LAYER != -1:
+            raise ValueError("native path supports MODEL.DINO.OUTPUT 'dense', LAYER -1, single layer")
+        D, L, heads = VIT_ARCH[name]
+        pos_grid, n_levels = 37, 3
+    elif backbone == "build_clip_backbone":
+        tower, patch = OVM_TOWER_CLIP, 16
+        name = cfg.MODEL.CLIP.ARCH
+        if name not in CLIP_ARCH:
+            raise ValueError(f"unsupported MODEL.CLIP.ARCH {name!r} (known: {sorted(CLIP_ARCH)})")
+        if cfg.MODEL.CLIP.OUTPUT != "dense" or cfg.MODEL.CLIP.RETURN_MULTILAYER or cfg.MODEL.CLIP.LAYER != -1:
+            raise ValueError("native path supports MODEL.CLIP.OUTPUT 'dense', LAYER -1, single layer")
+        D, L, heads, patch, pos_grid = CLIP_ARCH[name]
+        n_levels = 4
+    else:
+        raise ValueError(f"MODEL.BACKBONE.NAME {backbone!r} is not on the native path (build_dino_backbone, build_clip_backbone)")
     H = cfg.MODEL.ROI_CUBE_HEAD
     unsupported = []
     if H.Z_TYPE != "direct": unsupported.append("Z_TYPE")
@@ -39,31 +55,39 @@ def config_to_native(cfg) -> OvmConfig:
     if H.NUM_CONV: unsupported.append("NUM_CONV")
     if unsupported:
         raise ValueError("ROI_CUBE_HEAD settings outside the OVMono3D-LIFT path (Base.yaml:71-86): " + ", ".join(unsupported))
-    D, L, heads = VIT_ARCH[name]
     S = int(cfg.MODEL.FPN.SQUARE_PAD)
-    if S <= 0 or S % 14 != 0:
-        raise ValueError("MODEL.FPN.SQUARE_PAD must be a positive multiple of 14")
+    if S <= 0 or S % patch != 0:
+        raise ValueError(f"MODEL.FPN.SQUARE_PAD must be a positive multiple of {patch}")
     c = OvmConfig()
+    c.tower = tower
     c.embed_dim, c.depth, c.heads = D, L, heads
-    c.pos_grid = 37
+    c.pos_grid = pos_grid
     c.canvas = S
     c.fpn_channels = int(cfg.MODEL.FPN.OUT_CHANNELS)
-    c.use_depth_fusion = int(bool(cfg.MODEL.DINO.USE_DEPTH_FUSION))
+    c.use_depth_fusion = int(bool(cfg.MODEL.DINO.USE_DEPTH_FUSION)) if tower == OVM_TOWER_DINOV2 else 0
     for i in range(3):
         c.pixel_mean[i] = float(cfg.MODEL.PIXEL_MEAN[i])
         c.pixel_std[i] = float(cfg.MODEL.PIXEL_STD[i])
     c.num_classes = int(cfg.MODEL.ROI_HEADS.NUM_CLASSES)
     c.fc_dim = int(H.FC_DIM)
     c.pooler_res = int(H.POOLER_RESOLUTION)
-    c.pooler_min_level = int(cfg.MODEL.ROI_HEADS.POOLER_MIN_LEVEL)
-    c.pooler_max_level = int(cfg.MODEL.ROI_HEADS.POOLER_MAX_LEVEL)
+    if tower == OVM_TOWER_DINOV2:
+        # strides 7 / 14 / 28 are not powers of two: detectron2's ROIPooler level rule needs the fork's clamp
+        c.pooler_min_level = int(cfg.MODEL.ROI_HEADS.POOLER_MIN_LEVEL)
+        c.pooler_max_level = int(cfg.MODEL.ROI_HEADS.POOLER_MAX_LEVEL)
+    else:
+        # strides patch/4 .. 2*patch are powers of two: ROIPooler's own min_level = -log2(scale_0), max_level = -log2(scale_last)
+        c.pooler_min_level = int(np.log2(patch / 4))
+        c.pooler_max_level = int(np.log2(patch * 2))
     c.virtual_focal = float(H.VIRTUAL_FOCAL)
     sizes = [s[0] for s in cfg.MODEL.ANCHOR_GENERATOR.SIZES]
     ratios = list(cfg.MODEL.ANCHOR_GENERATOR.ASPECT_RATIOS[0])
-    if len(sizes) != 3 or len(ratios) != 3:
-        raise ValueError("native RPN expects 3 levels x 3 aspect ratios (OVMono3D_dinov2_SFP.yaml:35-36)")
-    for i in range(3):
+    if len(sizes) != n_levels or len(ratios) != 3:
+        raise ValueError(f"native RPN expects one anchor size per pyramid level ({n_levels}) x 3 aspect ratios "
+                         "(OVMono3D_dinov2_SFP.yaml:35-36, OVMono3D_clip_SFP.yaml:40-41)")
+    for i in range(n_levels):
         c.anchor_sizes[i] = float(sizes[i])
+    for i in range(3):
         c.anchor_ratios[i] = float(ratios[i])
     c.rpn_pre_topk = int(cfg.MODEL.RPN.PRE_NMS_TOPK_TEST)
     c.rpn_post_topk = int(cfg.MODEL.RPN.POST_NMS_TOPK_TEST)
@@ -94,8 +118,12 @@ class Engine:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self._lib = _lib.load()
         self._h = C.c_void_p()
-        self.G = self.ncfg.canvas // 14
+        self.patch = 16 if self.ncfg.tower == OVM_TOWER_CLIP else 14
+        self.G = self.ncfg.canvas // self.patch
         self.C = self.ncfg.fpn_channels
+        # pyramid levels, finest first: (name, side of the grid on the canvas, stride in pixels)
+        scales = (4.0, 2.0, 1.0, 0.5) if self.ncfg.tower == OVM_TOWER_CLIP else (2.0, 1.0, 0.5)
+        self.levels = [(f"p{2 + i}", int(self.G * sc), self.patch / sc) for i, sc in enumerate(scales)]      # G odd: MaxPool2 floors
 
     # ---- lifecycle ---------------------------------------------------------------------------
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor]) -> None:
@@ -173,15 +201,16 @@ class Engine:
         outs = [None, None, None]
         ptrs = [None, None, None]
         if export:
-            G, Cc = self.G, self.C
-            for i, g in enumerate((2 * G, G, G // 2)):
-                outs[i] = torch.empty((B, g, g, Cc), dtype=torch.float32, device=self.device)
+            for i, (_, g, _) in enumerate(self.levels[:3]):
+                outs[i] = torch.empty((B, g, g, self.C), dtype=torch.float32, device=self.device)
                 ptrs[i] = outs[i].data_ptr()
         rc = self._lib.ovm_backbone_forward(self._h, images, B, dp, dh, dw, ptrs[0], ptrs[1], ptrs[2], self._stream())
         check(rc, self._h, "ovm_backbone_forward")
         if export:
+            for name, g, _ in self.levels[3:]:                                  # p5 of the 4-level towers: read from the handle
+                outs.append(self.debug_tensor(name, B * g * g * self.C).view(B, g, g, self.C))
             # logical NCHW view over NHWC storage (the reference returns NCHW tensors, dino.py:170)
-            return {k: o.permute(0, 3, 1, 2) for k, o in zip(("p2", "p3", "p4"), outs)}
+            return {lv[0]: o.permute(0, 3, 1, 2) for lv, o in zip(self.levels, outs)}
         return None
 
     def debug_tensor(self, name: str, numel: int) -> torch.Tensor:

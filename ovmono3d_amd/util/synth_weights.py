@@ -31,6 +31,14 @@ VIT_ARCH = {
 }
 
 
+CLIP_ARCH = {
+    # open_clip name: (width, layers, heads, patch, pretrained position grid)   -- reference backbone/clip.py:19 (arch), open_clip model configs
+    "ViT-B-16": (768, 12, 12, 16, 14),
+    "ViT-L-16-d2": (1024, 2, 16, 16, 14),     # ViT-L width at depth 2 (not an open_clip model): wide-tower geometry for tests
+    "ViT-test-16": (256, 2, 4, 16, 7),        # tiny (not an open_clip model)
+}
+
+
 def _lin(g, out_f, in_f, std=None, bias_std=0.02):
     std = (1.0 / math.sqrt(in_f)) if std is None else std
     w = torch.randn(out_f, in_f, generator=g) * std
@@ -42,6 +50,8 @@ def synth_state_dict(model_name: str = "vitl14", num_classes: int = 50, fpn_chan
                      fc_dim: int = 1024, pooler_res: int = 7, seed: int = 0,
                      depth_fusion: bool = True, pos_grid: int = 37,
                      num_anchors: int = 3) -> Dict[str, torch.Tensor]:
+    if model_name in CLIP_ARCH:
+        return synth_clip_state_dict(model_name, num_classes, fpn_channels, fc_dim, pooler_res, seed, num_anchors)
     D, L, _ = VIT_ARCH[model_name]
     g = torch.Generator().manual_seed(seed)
     sd: Dict[str, torch.Tensor] = {}
@@ -71,15 +81,24 @@ def synth_state_dict(model_name: str = "vitl14", num_classes: int = 50, fpn_chan
         sd["backbone.net.depth_fusion.weight"] = w.view(D, D + 1, 1, 1).contiguous()
         sd["backbone.net.depth_fusion.bias"] = b
 
-    C = fpn_channels
+    _synth_neck_dino(sd, g, D, fpn_channels)
+    _synth_heads(sd, g, fpn_channels, num_classes, fc_dim, pooler_res, num_anchors)
+    return sd
 
-    def conv(cout, cin, k, std=None):
-        std = (1.0 / math.sqrt(cin * k * k)) if std is None else std
-        return torch.randn(cout, cin, k, k, generator=g) * std
 
-    def ln(prefix):
-        sd[prefix + ".weight"] = 0.5 + torch.rand(C, generator=g)
-        sd[prefix + ".bias"] = torch.randn(C, generator=g) * 0.05
+def _conv(g, cout, cin, k, std=None):
+    std = (1.0 / math.sqrt(cin * k * k)) if std is None else std
+    return torch.randn(cout, cin, k, k, generator=g) * std
+
+
+def _ln(sd, g, prefix, C):
+    sd[prefix + ".weight"] = 0.5 + torch.rand(C, generator=g)
+    sd[prefix + ".bias"] = torch.randn(C, generator=g) * 0.05
+
+
+def _synth_neck_dino(sd, g, D, C):
+    conv = lambda cout, cin, k, std=None: _conv(g, cout, cin, k, std)
+    ln = lambda prefix: _ln(sd, g, prefix, C)
 
     # p2: ConvT(D->D/2,k2,s2,bias) -> 1x1(D/2->C)+LN -> 3x3+LN   (nohup.out:565-575)
     sd["backbone.simfp_2.0.weight"] = torch.randn(D, D // 2, 2, 2, generator=g) * (1.0 / math.sqrt(D))
@@ -99,6 +118,10 @@ def synth_state_dict(model_name: str = "vitl14", num_classes: int = 50, fpn_chan
     sd["backbone.simfp_4.2.weight"] = conv(C, C, 3)
     ln("backbone.simfp_4.2.norm")
 
+
+
+def _synth_heads(sd, g, C, num_classes, fc_dim, pooler_res, num_anchors):
+    conv = lambda cout, cin, k, std=None: _conv(g, cout, cin, k, std)
     # RPN head (nohup.out:632-639)
     R = "proposal_generator.rpn_head."
     sd[R + "conv.weight"] = conv(C, C, 3)
@@ -132,4 +155,65 @@ def synth_state_dict(model_name: str = "vitl14", num_classes: int = 50, fpn_chan
     # parameters registered by ROIHeads3D.__init__ (roi_heads.py:118-129); unused with priors disabled
     sd[H + "priors_dims_per_cat"] = torch.ones(1, num_classes, 2, 3)
     sd[H + "priors_z_scales"] = torch.ones(num_classes, 1)
+
+
+def synth_clip_state_dict(arch: str = "ViT-B-16", num_classes: int = 50, fpn_channels: int = 256, fc_dim: int = 1024,
+                          pooler_res: int = 7, seed: int = 0, num_anchors: int = 3) -> Dict[str, torch.Tensor]:
+    """Random-init checkpoint with the key tree of the reference's CLIP variant: ``backbone.net.visual.*`` is open_clip's
+    VisionTransformer (held as ``self.visual``, reference backbone/clip.py:28; ln_post / proj exist in the module but the dense
+    tap never reaches them), ``backbone.simfp_{2..5}`` detectron2's SimpleFeaturePyramid with scale factors (4, 2, 1, 0.5)
+    (:155-166), then the same RPN / box / cube heads."""
+    D, L, _, P, M = CLIP_ARCH[arch]
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    V = "backbone.net.visual."
+    sd[V + "class_embedding"] = torch.randn(D, generator=g) * 0.02
+    sd[V + "positional_embedding"] = torch.randn(1 + M * M, D, generator=g) * 0.02
+    sd[V + "conv1.weight"] = torch.randn(D, 3, P, P, generator=g) * (1.0 / math.sqrt(3.0 * P * P))
+    sd[V + "ln_pre.weight"] = 0.5 + torch.rand(D, generator=g)
+    sd[V + "ln_pre.bias"] = torch.randn(D, generator=g) * 0.05
+    for i in range(L):
+        B = V + f"transformer.resblocks.{i}."
+        for n in ("ln_1", "ln_2"):
+            sd[B + n + ".weight"] = 0.5 + torch.rand(D, generator=g)
+            sd[B + n + ".bias"] = torch.randn(D, generator=g) * 0.05
+        sd[B + "attn.in_proj_weight"], sd[B + "attn.in_proj_bias"] = _lin(g, 3 * D, D, std=2.0 / math.sqrt(D))
+        sd[B + "attn.out_proj.weight"], sd[B + "attn.out_proj.bias"] = _lin(g, D, D, std=0.5 / math.sqrt(D))
+        sd[B + "mlp.c_fc.weight"], sd[B + "mlp.c_fc.bias"] = _lin(g, 4 * D, D)
+        sd[B + "mlp.c_proj.weight"], sd[B + "mlp.c_proj.bias"] = _lin(g, D, 4 * D, std=0.5 / math.sqrt(4 * D))
+    sd[V + "ln_post.weight"] = torch.ones(D)
+    sd[V + "ln_post.bias"] = torch.zeros(D)
+    sd[V + "proj"] = torch.randn(D, 512, generator=g) * 0.02
+    C = fpn_channels
+    conv = lambda cout, cin, k, std=None: _conv(g, cout, cin, k, std)
+    ln = lambda prefix: _ln(sd, g, prefix, C)
+    # p2 (scale 4): ConvT(D->D/2) . LN(D/2) . GELU . ConvT(D/2->D/4) . 1x1+LN . 3x3+LN
+    sd["backbone.simfp_2.0.weight"] = torch.randn(D, D // 2, 2, 2, generator=g) * (1.0 / math.sqrt(D))
+    sd["backbone.simfp_2.0.bias"] = torch.randn(D // 2, generator=g) * 0.02
+    sd["backbone.simfp_2.1.weight"] = 0.5 + torch.rand(D // 2, generator=g)
+    sd["backbone.simfp_2.1.bias"] = torch.randn(D // 2, generator=g) * 0.05
+    sd["backbone.simfp_2.3.weight"] = torch.randn(D // 2, D // 4, 2, 2, generator=g) * (1.0 / math.sqrt(D // 2))
+    sd["backbone.simfp_2.3.bias"] = torch.randn(D // 4, generator=g) * 0.02
+    sd["backbone.simfp_2.4.weight"] = conv(C, D // 4, 1)
+    ln("backbone.simfp_2.4.norm")
+    sd["backbone.simfp_2.5.weight"] = conv(C, C, 3)
+    ln("backbone.simfp_2.5.norm")
+    # p3 (scale 2): ConvT(D->D/2) . 1x1+LN . 3x3+LN
+    sd["backbone.simfp_3.0.weight"] = torch.randn(D, D // 2, 2, 2, generator=g) * (1.0 / math.sqrt(D))
+    sd["backbone.simfp_3.0.bias"] = torch.randn(D // 2, generator=g) * 0.02
+    sd["backbone.simfp_3.1.weight"] = conv(C, D // 2, 1)
+    ln("backbone.simfp_3.1.norm")
+    sd["backbone.simfp_3.2.weight"] = conv(C, C, 3)
+    ln("backbone.simfp_3.2.norm")
+    # p4 (scale 1): 1x1+LN . 3x3+LN
+    sd["backbone.simfp_4.0.weight"] = conv(C, D, 1)
+    ln("backbone.simfp_4.0.norm")
+    sd["backbone.simfp_4.1.weight"] = conv(C, C, 3)
+    ln("backbone.simfp_4.1.norm")
+    # p5 (scale 0.5): MaxPool . 1x1+LN . 3x3+LN
+    sd["backbone.simfp_5.1.weight"] = conv(C, D, 1)
+    ln("backbone.simfp_5.1.norm")
+    sd["backbone.simfp_5.2.weight"] = conv(C, C, 3)
+    ln("backbone.simfp_5.2.norm")
+    _synth_heads(sd, g, C, num_classes, fc_dim, pooler_res, num_anchors)
     return sd

@@ -12,7 +12,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from ovmono3d_amd.defaults import make_cfg  # noqa: E402
-from ovmono3d_amd.util.synth_weights import VIT_ARCH, synth_state_dict  # noqa: E402
+from ovmono3d_amd.util.synth_weights import CLIP_ARCH, VIT_ARCH, synth_state_dict  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
@@ -25,8 +25,27 @@ def build_cfg(model_name="vittest14", canvas=224, precision="f16x3", max_batch=2
     return make_cfg("OVMono3D_dinov2_SFP.yaml", opts)
 
 
+def build_clip_cfg(arch="ViT-test-16", canvas=256, precision="f16x3", max_batch=2, max_rois=1000, roi_heads="ROIHeads3D", extra=()):
+    opts = ["MODEL.CLIP.ARCH", arch, "MODEL.FPN.SQUARE_PAD", canvas, "MODEL.AMD.GEMM_PRECISION", precision,
+            "MODEL.AMD.MAX_BATCH", max_batch, "MODEL.AMD.MAX_ROIS", max_rois, "MODEL.ROI_HEADS.NAME", roi_heads]
+    opts += list(extra)
+    return make_cfg("OVMono3D_clip_SFP.yaml", opts)
+
+
 def oracle_params(cfg):
     from oracle.pipeline import OracleParams
+    if cfg.MODEL.BACKBONE.NAME == "build_clip_backbone":
+        D, L, h, patch, _ = CLIP_ARCH[cfg.MODEL.CLIP.ARCH]
+        return OracleParams(model_name=cfg.MODEL.CLIP.ARCH, tower="clip", embed_dim=D, depth=L, heads=h,
+                            square_pad=cfg.MODEL.FPN.SQUARE_PAD, pixel_mean=tuple(cfg.MODEL.PIXEL_MEAN),
+                            pixel_std=tuple(cfg.MODEL.PIXEL_STD), use_depth_fusion=False,
+                            strides=(patch // 4, patch // 2, patch, patch * 2),
+                            anchor_sizes=tuple(float(s[0]) for s in cfg.MODEL.ANCHOR_GENERATOR.SIZES),
+                            anchor_ratios=tuple(cfg.MODEL.ANCHOR_GENERATOR.ASPECT_RATIOS[0]),
+                            rpn_pre_topk=cfg.MODEL.RPN.PRE_NMS_TOPK_TEST, rpn_post_topk=cfg.MODEL.RPN.POST_NMS_TOPK_TEST,
+                            rpn_nms=cfg.MODEL.RPN.NMS_THRESH, score_thresh=cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST,
+                            nms_thresh=cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST, topk=cfg.TEST.DETECTIONS_PER_IMAGE,
+                            virtual_focal=cfg.MODEL.ROI_CUBE_HEAD.VIRTUAL_FOCAL, pooler_min_level=2, pooler_max_level=5)
     D, L, h = VIT_ARCH[cfg.MODEL.DINO.MODEL_NAME]
     return OracleParams(model_name=cfg.MODEL.DINO.MODEL_NAME, embed_dim=D, depth=L, heads=h,
                         square_pad=cfg.MODEL.FPN.SQUARE_PAD, pixel_mean=tuple(cfg.MODEL.PIXEL_MEAN),

@@ -8,7 +8,7 @@ oracle is the fp32 restatement in oracle/."""
 import pytest
 import torch
 
-from common import assert_close, build_cfg, oracle_params, synth_inputs
+from common import assert_close, build_cfg, build_clip_cfg, oracle_params, synth_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -19,7 +19,8 @@ FIELDS = ("pred_boxes", "scores", "pred_bbox3D", "pred_center_cam", "pred_center
 def _build(cfg, seed=1):
     from ovmono3d_amd.modeling import build_model
     from ovmono3d_amd.util.synth_weights import synth_state_dict
-    sd = synth_state_dict(cfg.MODEL.DINO.MODEL_NAME, num_classes=cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=seed)
+    name = cfg.MODEL.CLIP.ARCH if cfg.MODEL.BACKBONE.NAME == "build_clip_backbone" else cfg.MODEL.DINO.MODEL_NAME
+    sd = synth_state_dict(name, num_classes=cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=seed)
     model = build_model(cfg)
     model.load_state_dict(sd)
     return model, sd
@@ -182,3 +183,68 @@ def test_inference_on_dataset_empty_image_between_nonempty(device):
     assert [len(r["instances"]) for r in res] == [4, 0, 4] and [r["image_id"] for r in res] == [0, 1, 2]
     solo = model([inputs[2]])[0]["instances"]
     assert abs(res[2]["instances"][0]["score"] - float(solo.scores[0])) < 1e-7
+
+
+# ------------------------------------------------------------------------------------------ CLIP tower (BASELINE config 4)
+def test_clip_tower_tiny_oracle2d_and_rpn_paths(device):
+    """build_clip_backbone: open_clip-style tower (conv1 without bias, ln_pre, QuickGELU, LN eps 1e-5, antialiased pos-embed
+    resize 7 -> 16) + the 4-level pyramid (scale-4 stage ConvT . LN . GELU . ConvT) + 4-level ROIPooler / RPN, against the CPU
+    oracle (reference backbone/clip.py:62-166). Two image shapes; given boxes, then the RPN + box-head route."""
+    from oracle.pipeline import inference
+    cfg = build_clip_cfg("ViT-test-16", 256, "f16x3", max_batch=2)
+    model, sd = _build(cfg, seed=5)
+    inputs = synth_inputs(2, hw=((160, 224), (256, 192)), n_boxes=12, seed=31)
+    out = model(inputs)
+    ref, aux = inference(sd, inputs, oracle_params(cfg), return_aux=True)
+    model.backbone.export_features = True
+    feats = model.backbone(model.preprocess_image(inputs))
+    assert sorted(feats) == ["p2", "p3", "p4", "p5"] and tuple(feats["p2"].shape[-2:]) == (64, 64) and tuple(feats["p5"].shape[-2:]) == (8, 8)
+    for k in ("p2", "p3", "p4", "p5"):
+        assert_close(feats[k], aux["features"][k], 2e-4, k)
+    model.backbone.export_features = False
+    _compare(out, ref)
+    # RPN over four levels -> box head -> cube head
+    inputs2 = synth_inputs(2, hw=((192, 256), (256, 256)), n_boxes=0, seed=33, oracle2d=False)
+    out2 = model(inputs2)
+    ref2 = inference(sd, inputs2, oracle_params(cfg))
+    assert len(out2[0]["instances"]) > 0
+    _compare(out2, ref2)
+
+
+def test_clip_tower_refuses_prompt_depth(device):
+    """detectron2's SimpleFeaturePyramid.forward takes no depth; the fork would raise a TypeError at rcnn3d.py:97."""
+    cfg = build_clip_cfg("ViT-test-16", 256, "f16x3", max_batch=1)
+    model, sd = _build(cfg, seed=5)
+    inputs = synth_inputs(1, hw=((160, 224),), n_boxes=4, seed=31, depth=True)
+    with pytest.raises(TypeError):
+        model(inputs, prompt_depth=torch.stack([x["depth"] for x in inputs]))
+    from ovmono3d_amd.lib import OvmError
+    native, _keep = model.engine.make_images(inputs)
+    with pytest.raises(OvmError):
+        model.engine.backbone_forward(native, 1, inputs[0]["depth"][None])
+
+
+def test_clip_vitb16_canvas1024_config4_size(device):
+    """BASELINE config 4 at its own size: CLIP ViT-B/16 (12 layers, D = 768), SQUARE_PAD 1024 -> 64 x 64 patches (T = 4097, the
+    same token count as the headline ViT-L/896 run), p2..p5 = 256 / 128 / 64 / 32, one 608 x 1024-bounded image with 32 given
+    boxes, against the CPU oracle."""
+    from oracle.pipeline import inference
+    cfg = build_clip_cfg("ViT-B-16", 1024, "f16x3", max_batch=1, max_rois=64)
+    model, sd = _build(cfg, seed=0)
+    inputs = synth_inputs(1, hw=((608, 800),), orig_scale=1.0, n_boxes=32, seed=13)
+    # make sure every pyramid level is pooled from: ROIPooler level = floor(4 + log2(sqrt(area) / 224)) clamped to [2, 5]
+    o = inputs[0]["oracle2D"]
+    o["gt_bbox2D"][:4] = torch.tensor([[10.0, 10.0, 60.0, 50.0], [100.0, 80.0, 300.0, 260.0], [50.0, 40.0, 420.0, 400.0], [20.0, 10.0, 780.0, 600.0]])
+    import math
+    lv = {min(5, max(2, int(math.floor(4 + math.log2(math.sqrt(float((b[2] - b[0]) * (b[3] - b[1]))) / 224 + 1e-8))))) for b in o["gt_bbox2D"]}
+    assert lv == {2, 3, 4, 5}, lv
+    out = model(inputs)
+    torch.set_num_threads(16)
+    ref, aux = inference(sd, inputs, oracle_params(cfg), return_aux=True)
+    model.backbone.export_features = True
+    feats = model.backbone(model.preprocess_image(inputs))
+    assert tuple(feats["p2"].shape) == (1, 256, 256, 256) and tuple(feats["p5"].shape) == (1, 256, 32, 32)
+    for k in ("p2", "p3", "p4", "p5"):
+        e = assert_close(feats[k], aux["features"][k], 1e-3, k)
+        print(f"CLIP ViT-B/16 @1024 {k}: scale-relative error {e:.2e}")
+    _compare(out, ref)

@@ -32,7 +32,16 @@ def test_config_to_native_validation():
     from ovmono3d_amd.native import config_to_native
     c = config_to_native(build_cfg("vitl14", 896))
     assert (c.embed_dim, c.depth, c.heads, c.canvas, c.precision) == (1024, 24, 16, 896, 3)
-    assert list(c.anchor_sizes) == [64.0, 256.0, 512.0] and c.rpn_pre_topk == 1000
+    assert list(c.anchor_sizes)[:3] == [64.0, 256.0, 512.0] and c.rpn_pre_topk == 1000 and c.tower == 0
+    from common import build_clip_cfg
+    k = config_to_native(build_clip_cfg("ViT-B-16", 1024))
+    assert (k.tower, k.embed_dim, k.depth, k.heads, k.canvas, k.pos_grid) == (1, 768, 12, 12, 1024, 14)
+    assert list(k.anchor_sizes) == [64.0, 128.0, 256.0, 512.0] and (k.pooler_min_level, k.pooler_max_level) == (2, 5)
+    assert k.use_depth_fusion == 0
+    with pytest.raises(ValueError):
+        config_to_native(build_clip_cfg("ViT-B-16", 1000))             # not a multiple of 16
+    with pytest.raises(ValueError):
+        config_to_native(build_cfg(extra=["MODEL.BACKBONE.NAME", "build_mae_backbone"]))
     with pytest.raises(ValueError):
         config_to_native(build_cfg("vitl14", 900))                    # not a multiple of 14
     with pytest.raises(ValueError):
@@ -129,3 +138,20 @@ def test_wordpiece_tokenizer_and_caption(tmp_path):
     assert tok.tokenize("zebra") == ["[UNK]"]
     with pytest.raises(AssertionError):
         phrase_spans(ids, [[5], [99]])
+
+
+@pytest.mark.parametrize("M,G", [(14, 64), (14, 16), (7, 16), (14, 10), (14, 7), (14, 14)])
+def test_clip_pos_embed_resize_matches_torch_antialiased_bicubic(M, G):
+    """ovm_host_resize_pos_embed_aa == F.interpolate(size, bicubic, align_corners=False, antialias=True) on the patch rows
+    (reference clip.py:98-133), for up-sampling (the shipped case 14 -> 64), down-sampling and the no-op."""
+    from oracle.clip_vit import resize_pos_embed
+    from ovmono3d_amd import lib
+    L = lib.load()
+    D = 24
+    pos = torch.randn(1 + M * M, D, generator=torch.Generator().manual_seed(M * 100 + G))
+    ref = resize_pos_embed(pos, (G, G))
+    out = np.empty((1 + G * G, D), np.float32)
+    src = np.ascontiguousarray(pos.numpy())
+    assert L.ovm_host_resize_pos_embed_aa(src.ctypes.data, M, D, G, out.ctypes.data) == 0
+    assert np.abs(out - ref.numpy()).max() < 2e-6
+    assert np.array_equal(out[0], src[0])                                     # class row untouched

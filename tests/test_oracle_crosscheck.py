@@ -181,3 +181,88 @@ def test_virtual_depth_scale():
     # same focal / height as the virtual camera -> scale 1 (math_util.py:581-592)
     assert OH.compute_virtual_scale_from_focal_spaces(512.0, 512.0, 512.0, 512.0) == 1.0
     assert OH.compute_virtual_scale_from_focal_spaces(1024.0, 512.0, 512.0, 532.0) == pytest.approx(2 * 532 / 512)
+
+
+def _hf_clip_from_open_clip_keys(sd, D, L, heads, patch, grid, pos_table):
+    """Hugging Face CLIPVisionModel (random-init, no download) carrying an open_clip-keyed tower; the position table is given
+    already resized so that both sides see the same embedding (the resize itself is tested against F.interpolate in
+    test_host.py)."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    cfg = CLIPVisionConfig(hidden_size=D, intermediate_size=4 * D, num_hidden_layers=L, num_attention_heads=heads, num_channels=3,
+                           image_size=grid * patch, patch_size=patch, hidden_act="quick_gelu", layer_norm_eps=1e-5,
+                           attn_implementation="eager")
+    m = CLIPVisionModel(cfg).eval()
+    V = "backbone.net.visual."
+    hf = {"vision_model.embeddings.class_embedding": sd[V + "class_embedding"],
+          "vision_model.embeddings.patch_embedding.weight": sd[V + "conv1.weight"],
+          "vision_model.embeddings.position_embedding.weight": pos_table,
+          "vision_model.pre_layrnorm.weight": sd[V + "ln_pre.weight"], "vision_model.pre_layrnorm.bias": sd[V + "ln_pre.bias"],
+          "vision_model.post_layernorm.weight": sd[V + "ln_post.weight"], "vision_model.post_layernorm.bias": sd[V + "ln_post.bias"]}
+    for i in range(L):
+        s, d = V + f"transformer.resblocks.{i}.", f"vision_model.encoder.layers.{i}."
+        wq, wk, wv = sd[s + "attn.in_proj_weight"].chunk(3, 0)
+        bq, bk, bv = sd[s + "attn.in_proj_bias"].chunk(3, 0)
+        for n, w, b in (("q", wq, bq), ("k", wk, bk), ("v", wv, bv)):
+            hf[d + f"self_attn.{n}_proj.weight"], hf[d + f"self_attn.{n}_proj.bias"] = w, b
+        hf[d + "self_attn.out_proj.weight"], hf[d + "self_attn.out_proj.bias"] = sd[s + "attn.out_proj.weight"], sd[s + "attn.out_proj.bias"]
+        hf[d + "layer_norm1.weight"], hf[d + "layer_norm1.bias"] = sd[s + "ln_1.weight"], sd[s + "ln_1.bias"]
+        hf[d + "layer_norm2.weight"], hf[d + "layer_norm2.bias"] = sd[s + "ln_2.weight"], sd[s + "ln_2.bias"]
+        hf[d + "mlp.fc1.weight"], hf[d + "mlp.fc1.bias"] = sd[s + "mlp.c_fc.weight"], sd[s + "mlp.c_fc.bias"]
+        hf[d + "mlp.fc2.weight"], hf[d + "mlp.fc2.bias"] = sd[s + "mlp.c_proj.weight"], sd[s + "mlp.c_proj.bias"]
+    if not any(k.startswith("vision_model.") for k in m.state_dict()):          # key prefix differs between transformers releases
+        hf = {k[len("vision_model."):]: v for k, v in hf.items()}
+    missing, unexpected = m.load_state_dict(hf, strict=False)
+    assert not unexpected and all("position_ids" in k for k in missing), (missing, unexpected)
+    return m
+
+
+def test_clip_tower_matches_hf_clip_vision_model():
+    """oracle/clip_vit.py (the reference's CLIPBackbone.forward over open_clip's tower) against an independent implementation of
+    the same architecture: conv1 without bias, class token, ln_pre, pre-norm blocks with QuickGELU, last block's patch tokens
+    before any final norm. Same weights, same (already resized) position table."""
+    from oracle import clip_vit
+    from ovmono3d_amd.util.synth_weights import CLIP_ARCH, synth_clip_state_dict
+    arch = "ViT-test-16"
+    D, L, heads, patch, M = CLIP_ARCH[arch]
+    sd = synth_clip_state_dict(arch, seed=11)
+    grid = 12
+    x = torch.randn(2, 3, grid * patch, grid * patch, generator=torch.Generator().manual_seed(0))
+    dense = clip_vit.clip_backbone_forward(sd, x, heads, L)
+    assert dense.shape == (2, D, grid, grid)
+    pos = clip_vit.resize_pos_embed(sd["backbone.net.visual.positional_embedding"], (grid, grid))
+    m = _hf_clip_from_open_clip_keys(sd, D, L, heads, patch, grid, pos)
+    with torch.no_grad():
+        hs = m(pixel_values=x, output_hidden_states=True).hidden_states[-1]   # last encoder layer, before post_layernorm
+    ref = hs[:, 1:].reshape(2, grid, grid, D).permute(0, 3, 1, 2)
+    assert float((dense - ref).abs().max() / ref.abs().max()) < 2e-5
+    # native grid: the table is used as it is
+    x14 = torch.randn(1, 3, M * patch, M * patch, generator=torch.Generator().manual_seed(1))
+    assert clip_vit.resize_pos_embed(sd["backbone.net.visual.positional_embedding"], (M, M)) is sd["backbone.net.visual.positional_embedding"]
+    d14 = clip_vit.clip_backbone_forward(sd, x14, heads, L)
+    m14 = _hf_clip_from_open_clip_keys(sd, D, L, heads, patch, M, sd["backbone.net.visual.positional_embedding"])
+    with torch.no_grad():
+        h14 = m14(pixel_values=x14, output_hidden_states=True).hidden_states[-1]
+    assert float((d14 - h14[:, 1:].reshape(1, M, M, D).permute(0, 3, 1, 2)).abs().max() / h14.abs().max()) < 2e-5
+
+
+def test_sfp4_stage_shapes_and_scale4_branch():
+    """The 4-level pyramid of the CLIP config: strides P/4, P/2, P, 2P; the scale-4 branch is ConvT . LN . GELU . ConvT, checked
+    against torch modules wired the way detectron2's SimpleFeaturePyramid builds them."""
+    from ovmono3d_amd.util.synth_weights import CLIP_ARCH, synth_clip_state_dict
+    sd = synth_clip_state_dict("ViT-test-16", seed=4, fpn_channels=64)
+    D = CLIP_ARCH["ViT-test-16"][0]
+    feat = torch.randn(1, D, 6, 6, generator=torch.Generator().manual_seed(2))
+    out = sfp.sfp4_forward(sd, feat)
+    assert {k: tuple(v.shape) for k, v in out.items()} == {"p2": (1, 64, 24, 24), "p3": (1, 64, 12, 12), "p4": (1, 64, 6, 6), "p5": (1, 64, 3, 3)}
+    up1 = torch.nn.ConvTranspose2d(D, D // 2, 2, 2); up2 = torch.nn.ConvTranspose2d(D // 2, D // 4, 2, 2)
+    c1 = torch.nn.Conv2d(D // 4, 64, 1, bias=False); c3 = torch.nn.Conv2d(64, 64, 3, padding=1, bias=False)
+    with torch.no_grad():
+        up1.weight.copy_(sd["backbone.simfp_2.0.weight"]); up1.bias.copy_(sd["backbone.simfp_2.0.bias"])
+        up2.weight.copy_(sd["backbone.simfp_2.3.weight"]); up2.bias.copy_(sd["backbone.simfp_2.3.bias"])
+        c1.weight.copy_(sd["backbone.simfp_2.4.weight"]); c3.weight.copy_(sd["backbone.simfp_2.5.weight"])
+        y = up1(feat)
+        y = F.layer_norm(y.permute(0, 2, 3, 1), (D // 2,), sd["backbone.simfp_2.1.weight"], sd["backbone.simfp_2.1.bias"], 1e-6).permute(0, 3, 1, 2)
+        y = up2(F.gelu(y))
+        y = F.layer_norm(c1(y).permute(0, 2, 3, 1), (64,), sd["backbone.simfp_2.4.norm.weight"], sd["backbone.simfp_2.4.norm.bias"], 1e-6).permute(0, 3, 1, 2)
+        y = F.layer_norm(c3(y).permute(0, 2, 3, 1), (64,), sd["backbone.simfp_2.5.norm.weight"], sd["backbone.simfp_2.5.norm.bias"], 1e-6).permute(0, 3, 1, 2)
+    assert float((out["p2"] - y).abs().max()) < 1e-4
