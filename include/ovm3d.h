@@ -343,6 +343,11 @@ int ovm_resize_bilinear_u8(const uint8_t* src, int32_t H, int32_t W, int32_t C, 
                            const int32_t* xbounds, const int32_t* xcoefs, int32_t xksize, const int32_t* ybounds, const int32_t* ycoefs,
                            int32_t yksize, uint8_t* tmp, uint8_t* dst, ovm_stream_t stream);
 
+/* fp32 bilinear resize, align_corners=False, no antialias: torch.nn.functional.interpolate(mode="bilinear") as the reference's
+ * mapper applies it to a depth prompt (cubercnn/data/dataset_mapper.py:45-52 to the image size, :70-72 through ResizeShortestEdge
+ * - detectron2's ResizeTransform takes this route for non-uint8 arrays). src [B][H][W] dense, dst [B][outH][outW], device. */
+int ovm_resize_bilinear_f32(const float* src, int32_t B, int32_t H, int32_t W, int32_t outH, int32_t outW, float* dst, ovm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

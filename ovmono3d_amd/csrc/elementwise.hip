@@ -306,16 +306,20 @@ int launch_maxpool2(const half_t* Ihi, const half_t* Ilo, int B, int G, int D, h
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 
-// Bilinear resize (align_corners=False, no antialias) of depth prompts [B][1][Hd][Wd] -> [B][G*G]
-// (F.interpolate(mode='bilinear') at reference dino.py:85).
-__global__ void depth_resize_kernel(const float* __restrict__ Dp, int B, int Hd, int Wd, int G, float* __restrict__ out) {
+// Bilinear resize (align_corners=False, no antialias) of fp32 planes [B][Hd][Wd] -> [B][Ho][Wo]: F.interpolate(mode='bilinear')
+// as the reference applies it to depth prompts - to the image size and through ResizeShortestEdge in the mapper
+// (dataset_mapper.py:45-52,70-72: detectron2's ResizeTransform uses F.interpolate for non-uint8 input), then to the token grid
+// in the backbone (dino.py:85).
+__global__ void resize_bilinear_f32_kernel(const float* __restrict__ Dp, int B, int Hd, int Wd, int Ho, int Wo, float* __restrict__ out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * G * G) return;
-  const int x = idx % G; const int t = idx / G; const int y = t % G; const int b = t / G;
-  const float sy = (float)Hd / (float)G, sx = (float)Wd / (float)G;
+  if (idx >= B * Ho * Wo) return;
+  const int x = idx % Wo; const int t = idx / Wo; const int y = t % Ho; const int b = t / Ho;
+  const float sy = (float)Hd / (float)Ho, sx = (float)Wd / (float)Wo;
   float fy = ((float)y + 0.5f) * sy - 0.5f; if (fy < 0.f) fy = 0.f;
   float fx = ((float)x + 0.5f) * sx - 0.5f; if (fx < 0.f) fx = 0.f;
-  const int y0 = (int)fy, x0 = (int)fx;
+  int y0 = (int)fy, x0 = (int)fx;
+  if (y0 > Hd - 1) y0 = Hd - 1;
+  if (x0 > Wd - 1) x0 = Wd - 1;
   const int y1 = y0 + ((y0 < Hd - 1) ? 1 : 0), x1 = x0 + ((x0 < Wd - 1) ? 1 : 0);
   const float ly = fy - (float)y0, lx = fx - (float)x0;
   const float* d = Dp + (size_t)b * Hd * Wd;
@@ -323,10 +327,14 @@ __global__ void depth_resize_kernel(const float* __restrict__ Dp, int B, int Hd,
                   ly * ((1.f - lx) * d[y1 * Wd + x0] + lx * d[y1 * Wd + x1]);
   out[idx] = v;
 }
-int launch_depth_resize(const float* Dp, int B, int Hd, int Wd, int G, float* out, hipStream_t s) {
-  const int total = B * G * G;
-  hipLaunchKernelGGL(depth_resize_kernel, dim3((total + 255) / 256), dim3(256), 0, s, Dp, B, Hd, Wd, G, out);
+int launch_resize_bilinear_f32(const float* src, int B, int Hd, int Wd, int Ho, int Wo, float* out, hipStream_t s) {
+  if (B < 1 || Hd < 1 || Wd < 1 || Ho < 1 || Wo < 1) return OVM_ERR_INVALID;
+  const int total = B * Ho * Wo;
+  hipLaunchKernelGGL(resize_bilinear_f32_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, B, Hd, Wd, Ho, Wo, out);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
+int launch_depth_resize(const float* Dp, int B, int Hd, int Wd, int G, float* out, hipStream_t s) {
+  return launch_resize_bilinear_f32(Dp, B, Hd, Wd, G, G, out, s);
 }
 
 // zero-fill helper for split fp16 / fp32 buffers on a stream

@@ -75,6 +75,7 @@ int launch_tokens_cast(const float* X, int B, int T, int G2, int D, int ldo, con
 int launch_tokens_writeback(float* X, const float* F, int B, int T, int G2, int D, hipStream_t s);
 int launch_maxpool2(const half_t* Ihi, const half_t* Ilo, int B, int G, int D, half_t* Ohi, half_t* Olo, hipStream_t s);
 int launch_depth_resize(const float* Dp, int B, int Hd, int Wd, int G, float* out, hipStream_t s);
+int launch_resize_bilinear_f32(const float* src, int B, int Hd, int Wd, int Ho, int Wo, float* out, hipStream_t s);
 int launch_zero(void* p, size_t bytes, hipStream_t s);
 int launch_attention(const AttnParams& p, int npass, hipStream_t s);
 void attn_set_tail_rows(int on);

@@ -10,6 +10,8 @@
 #include <cmath>
 #include <cstdint>
 #include <vector>
+
+#include "kernels.hpp"
 #include "common.hpp"
 #include "../../include/ovm3d.h"
 
@@ -131,6 +133,11 @@ int ovm_resize_bilinear_u8(const uint8_t* src, int32_t H, int32_t W, int32_t C, 
     if (hipMemcpyAsync(dst, src, (size_t)H * W * C, hipMemcpyDeviceToDevice, s) != hipSuccess) return OVM_ERR_HIP;
   }
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
+
+int ovm_resize_bilinear_f32(const float* src, int32_t B, int32_t H, int32_t W, int32_t outH, int32_t outW, float* dst, ovm_stream_t stream) {
+  if (!src || !dst) return OVM_ERR_INVALID;
+  return ovm::launch_resize_bilinear_f32(src, B, H, W, outH, outW, dst, (hipStream_t)stream);
 }
 
 }  // extern "C"

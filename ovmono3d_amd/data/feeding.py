@@ -98,8 +98,9 @@ class DatasetMapper3D:
         # device-side ResizeShortestEdge (bit-identical to the Pillow path; gpu_resize.py) when a HIP device is present
         self.gpu_resize = None
         if bool(cfg.MODEL.AMD.get("GPU_RESIZE", False)) and str(cfg.MODEL.DEVICE).startswith("cuda") and torch.cuda.is_available():
-            from .gpu_resize import ResizeShortestEdgeGPU
+            from .gpu_resize import DepthPromptResizeGPU, ResizeShortestEdgeGPU
             self.gpu_resize = ResizeShortestEdgeGPU(cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
+            self.gpu_depth_resize = DepthPromptResizeGPU(cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
 
     def __call__(self, d: Dict) -> Dict:
         d = dict(d)
@@ -109,7 +110,9 @@ class DatasetMapper3D:
             base = os.path.splitext(os.path.basename(d["file_name"]))[0]
             try:
                 depth = np.load(os.path.join(self.depth_dir, "test", base + ".npz"))["depth"].astype("float32")
-                if depth.shape[:2] != image.shape[:2]:
+                if self.gpu_resize is not None:
+                    pass                                                       # both resizes run on the device below
+                elif depth.shape[:2] != image.shape[:2]:
                     depth = torch.nn.functional.interpolate(torch.from_numpy(depth)[None, None], size=image.shape[:2],
                                                             mode="bilinear", align_corners=False)[0, 0].numpy()
             except Exception:
@@ -119,7 +122,9 @@ class DatasetMapper3D:
         else:
             image = self.resize(image)
             d["image"] = torch.as_tensor(np.ascontiguousarray(image.transpose(2, 0, 1)))
-        if depth is not None:
+        if depth is not None and self.gpu_resize is not None:
+            d["depth"] = self.gpu_depth_resize(torch.from_numpy(np.ascontiguousarray(depth)).cuda(), image.shape[:2]).unsqueeze(0)
+        elif depth is not None:
             d["depth"] = torch.as_tensor(np.ascontiguousarray(self.resize(depth))).unsqueeze(0)
         return d
 

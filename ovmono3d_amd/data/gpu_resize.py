@@ -84,3 +84,37 @@ class ResizeShortestEdgeGPU:
     def __call__(self, img: torch.Tensor) -> torch.Tensor:
         nh, nw = self._shape(int(img.shape[0]), int(img.shape[1]))
         return resize_bilinear_u8(img, nh, nw)
+
+
+def resize_bilinear_f32(x: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
+    """x: float32 [H, W] or [B, H, W] on the HIP device -> [out_h, out_w] / [B, out_h, out_w]:
+    ``F.interpolate(x, (out_h, out_w), mode="bilinear", align_corners=False)`` (the depth-prompt resizes of the reference's mapper,
+    dataset_mapper.py:45-52,70-72). No CPU fallback."""
+    if x.device.type != "cuda" or x.dtype != torch.float32 or x.dim() not in (2, 3):
+        raise RuntimeError("resize_bilinear_f32 takes a float32 [H, W] or [B, H, W] tensor on the HIP device (no CPU fallback)")
+    L = _lib.load()
+    squeeze = x.dim() == 2
+    x = (x[None] if squeeze else x).contiguous()
+    B, H, W = (int(v) for v in x.shape)
+    if (H, W) == (int(out_h), int(out_w)):
+        return x[0].clone() if squeeze else x.clone()
+    out = torch.empty((B, int(out_h), int(out_w)), dtype=torch.float32, device=x.device)
+    stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(L.ovm_resize_bilinear_f32(x.data_ptr(), B, H, W, int(out_h), int(out_w), out.data_ptr(), stream), what="ovm_resize_bilinear_f32")
+    return out[0] if squeeze else out
+
+
+class DepthPromptResizeGPU:
+    """The two resizes the reference's mapper applies to a depth prompt, on the device: to the image's size when the stored map
+    has another one (dataset_mapper.py:45-52), then ResizeShortestEdge's output size (:70-72)."""
+
+    def __init__(self, short_edge_length: int, max_size: int):
+        from .feeding import ResizeShortestEdge
+        self._shape = ResizeShortestEdge(short_edge_length, max_size).output_shape
+
+    def __call__(self, depth: torch.Tensor, image_hw) -> torch.Tensor:
+        h, w = int(image_hw[0]), int(image_hw[1])
+        if tuple(depth.shape[-2:]) != (h, w):
+            depth = resize_bilinear_f32(depth, h, w)
+        nh, nw = self._shape(h, w)
+        return resize_bilinear_f32(depth, nh, nw) if (nh, nw) != (h, w) else depth

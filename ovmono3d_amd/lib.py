@@ -65,7 +65,7 @@ EXPORTS = [
     "ovm_backbone_num_levels", "ovm_backbone_level",
     "ovm_op_split_f16", "ovm_op_interleave", "ovm_op_gemm", "ovm_op_layernorm", "ovm_op_attention", "ovm_op_roi_align",
     "ovm_op_cube_decode", "ovm_op_nms", "ovm_debug_copy", "ovm_set_corun", "ovm_profile_enable", "ovm_profile_read",
-    "ovm_comm_unique_id", "ovm_comm_init", "ovm_comm_destroy", "ovm_tune_set", "ovm_gdino_postprocess", "ovm_box3d_iou", "ovm_host_pil_bilinear_coeffs", "ovm_resize_bilinear_u8",
+    "ovm_comm_unique_id", "ovm_comm_init", "ovm_comm_destroy", "ovm_tune_set", "ovm_gdino_postprocess", "ovm_box3d_iou", "ovm_host_pil_bilinear_coeffs", "ovm_resize_bilinear_u8", "ovm_resize_bilinear_f32",
     "ovm_g_pack_weight", "ovm_g_linear", "ovm_g_layernorm", "ovm_g_bmm", "ovm_g_bmm2", "ovm_g_softmax", "ovm_g_softmax2", "ovm_g_eltwise", "ovm_g_gather_rows",
     "ovm_g_groupnorm", "ovm_g_msdeform", "ovm_g_sine_embed", "ovm_g_normalize_image", "ovm_g_topk", "ovm_g_rowmax",
     "ovm_gdino_create", "ovm_gdino_destroy", "ovm_gdino_last_error", "ovm_gdino_forward", "ovm_gdino_detect", "ovm_gdino_set_force_topk",
@@ -127,6 +127,7 @@ def load() -> C.CDLL:
     lib.ovm_debug_set_ptr.argtypes = [C.c_char_p, vp]
     lib.ovm_host_pil_bilinear_coeffs.argtypes = [i32, i32, vp, vp, i32]
     lib.ovm_resize_bilinear_u8.argtypes = [vp, i32, i32, i32, i64, i64, i64, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp]
+    lib.ovm_resize_bilinear_f32.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     lib.ovm_box3d_iou.argtypes = [vp, vp, i32, i32, f32, f32, vp, vp, vp]
     lib.ovm_g_pack_weight.argtypes = [vp, i32, i32, i32, vp, vp, vp]
     lib.ovm_g_linear.argtypes = [vp, i32, i32, i32, vp, vp, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp]

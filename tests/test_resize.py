@@ -62,3 +62,42 @@ def test_resize_shortest_edge_gpu_matches_host_feeding(device):
         ref = ResizeShortestEdge(532, 896)(img)
         got = ResizeShortestEdgeGPU(532, 896)(torch.from_numpy(img).to(device)).cpu().numpy()
         assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_depth_prompt_resize_on_device_matches_the_reference_mapper(device, tmp_path):
+    """ovm_resize_bilinear_f32 == F.interpolate(bilinear, align_corners=False) (up, down, non-integer ratios), and the mapper with
+    MODEL.AMD.GPU_RESIZE feeds the same depth prompt as the host mapper: stored map of another size -> image size ->
+    ResizeShortestEdge's size (reference dataset_mapper.py:38-72)."""
+    import os
+    from PIL import Image
+    from common import build_cfg
+    from ovmono3d_amd.data.feeding import DatasetMapper3D
+    from ovmono3d_amd.data.gpu_resize import resize_bilinear_f32
+    g = torch.Generator().manual_seed(3)
+    for (h, w), (oh, ow) in (((60, 80), (480, 640)), ((480, 640), (37, 37)), ((375, 1242), (270, 896)), ((33, 47), (33, 90)), ((5, 7), (5, 7))):
+        x = torch.rand(2, h, w, generator=g) * 7.0
+        ref = torch.nn.functional.interpolate(x[:, None], (oh, ow), mode="bilinear", align_corners=False)[:, 0]
+        got = resize_bilinear_f32(x.to(device), oh, ow).cpu()
+        assert got.shape == ref.shape and float((got - ref).abs().max()) < 2e-6 * 7.0
+    with pytest.raises(RuntimeError):
+        resize_bilinear_f32(torch.zeros(4, 4), 2, 2)                           # host tensor: no CPU fallback
+    # the mapper: image 300 x 400, depth stored at 150 x 200
+    (tmp_path / "depth" / "test").mkdir(parents=True)
+    rng = np.random.default_rng(1)
+    Image.fromarray(rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)).save(tmp_path / "im0.png")
+    np.savez(tmp_path / "depth" / "test" / "im0.npz", depth=(rng.random((150, 200)) * 5).astype(np.float32))
+    rec = {"file_name": str(tmp_path / "im0.png"), "height": 300, "width": 400, "K": np.eye(3).tolist(), "image_id": 0}
+    host = DatasetMapper3D(build_cfg("vittest14", 224, extra=["INPUT.MIN_SIZE_TEST", 168, "INPUT.MAX_SIZE_TEST", 224, "MODEL.AMD.GPU_RESIZE", False]),
+                           False, str(tmp_path / "depth"))(rec)
+    assert host["depth"].device.type == "cpu"
+    dev = DatasetMapper3D(build_cfg("vittest14", 224, extra=["INPUT.MIN_SIZE_TEST", 168, "INPUT.MAX_SIZE_TEST", 224, "MODEL.AMD.GPU_RESIZE", True,
+                                                              "MODEL.DEVICE", "cuda"]), False, str(tmp_path / "depth"))(rec)
+    assert dev["depth"].device.type == "cuda" and tuple(dev["depth"].shape) == tuple(host["depth"].shape) == (1, 168, 224)
+    assert float((dev["depth"].cpu() - host["depth"]).abs().max()) < 1e-5
+    assert torch.equal(dev["image"].cpu(), host["image"])
+    # a missing depth file gives the reference's all-zero prompt on both routes (dataset_mapper.py:53-55)
+    os.remove(tmp_path / "depth" / "test" / "im0.npz")
+    z = DatasetMapper3D(build_cfg("vittest14", 224, extra=["INPUT.MIN_SIZE_TEST", 168, "INPUT.MAX_SIZE_TEST", 224, "MODEL.AMD.GPU_RESIZE", True,
+                                                            "MODEL.DEVICE", "cuda"]), False, str(tmp_path / "depth"))(rec)
+    assert tuple(z["depth"].shape) == (1, 168, 224) and float(z["depth"].abs().max()) == 0.0
