@@ -53,6 +53,12 @@ struct Plan;
 
 }  // namespace
 
+namespace ovm {
+static int g_gdino_branches = 1;
+void set_gdino_branches(int v) { g_gdino_branches = v ? 1 : 0; }
+}  // namespace ovm
+using ovm::g_gdino_branches;
+
 struct OvmGdino {
   OvmGdinoConfig cfg;
   int device = 0, npass = 3;
@@ -78,6 +84,11 @@ struct OvmGdino {
   const int* force_topk = nullptr;            // device int32 [num_queries] (tests: pin the two-stage selection)
   int graphs_enabled = 1;
   long launches_last = 0;
+  // ---- second branch of the forward: the text side (BERT, the text enhancers) has no data dependence on the image side (Swin,
+  // deformable attention) between their joins, so it runs on a stream of its own - in a captured plan two branches of the graph
+  int branches = 1;                           // ovm_tune_set("gdino_branches", 0 | 1)
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace {
@@ -489,6 +500,10 @@ int build_plan(OvmGdino* g, int H, int W, const std::vector<int>& ids, const std
   return OVM_OK;
 }
 
+// split-K workspace of the text branch (tail of the plan's workspace): its largest user is BERT's output projection at the
+// maximum caption length, 12 slices x 256 tokens x 768 columns of fp32 partials = 9.4 MB
+constexpr size_t kAuxWs = (size_t)16 << 20;
+
 // ------------------------------------------------------------------------------------------------------------------------------
 // One forward over a plan. `dry` = size the arena only (no launches).
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -497,6 +512,25 @@ struct Run {
   size_t off = 0, peak = 0;
   long launches = 0;
   int rc = OVM_OK;
+  // the two branches (see OvmGdino::aux). `s` is the stream the op wrappers launch on; fork() lets the text branch start from
+  // the current point of the main stream, join() makes the main stream wait for it. Each branch has its own slice of the split-K
+  // workspace. With branches off (or in the sizing pass) everything stays on the caller's stream.
+  hipStream_t s_main = nullptr;
+  float* ws = nullptr; size_t ws_cap = 0;
+  bool two() const { return g->branches && g->aux && !dry; }
+  void init_streams() { s_main = s; ws = pl->gemm_ws; ws_cap = two() ? pl->gemm_ws_cap - kAuxWs : pl->gemm_ws_cap; }
+  void fork() {
+    if (!two() || rc != OVM_OK) return;
+    if (hipEventRecord(g->ev_fork, s_main) != hipSuccess || hipStreamWaitEvent(g->aux, g->ev_fork, 0) != hipSuccess) fail(OVM_ERR_HIP, "fork");
+  }
+  void on_text() { if (two()) { s = g->aux; ws = (float*)((char*)pl->gemm_ws + (pl->gemm_ws_cap - kAuxWs)); ws_cap = kAuxWs; } }
+  void on_image() { if (two()) { s = s_main; ws = pl->gemm_ws; ws_cap = pl->gemm_ws_cap - kAuxWs; } }
+  void join() {
+    if (!two()) return;
+    on_image();
+    if (rc != OVM_OK) return;
+    if (hipEventRecord(g->ev_join, g->aux) != hipSuccess || hipStreamWaitEvent(s_main, g->ev_join, 0) != hipSuccess) fail(OVM_ERR_HIP, "join");
+  }
 
   void* alloc(size_t bytes) {
     off = (off + 255) & ~(size_t)255;
@@ -536,7 +570,7 @@ struct Run {
   GemmParams gp(const SplitBuf& A, int M, const Lin& W) {
     GemmParams p; memset(&p, 0, sizeof(p));
     p.Ahi = A.hi; p.Alo = A.lo; p.lda = A.ld; p.Whi = W.hi; p.Wlo = W.lo; p.M = M; p.N = W.N; p.K = W.Kpad; p.bias = W.bias;
-    p.ws_slot = 1; p.part_ws = pl->gemm_ws; p.part_cap = pl->gemm_ws_cap;
+    p.ws_slot = 1; p.part_ws = ws; p.part_cap = ws_cap;
     return p;
   }
   void gemm(const GemmParams& p, int epi) { if (go()) chk(launch_gemm(p, g->npass, epi, A_ROWMAJOR, s), "gemm"); }
@@ -545,7 +579,7 @@ struct Run {
   void lin(const float* A, const float* A2, int lda, int M, const Lin& W, int act, const float* R, int ldr, float* C, int ldc) {
     if (!go() || M <= 0) return;
     if (!gemm_small_supported(A, lda, W.K) || (A2 && (((uintptr_t)A2) & 15))) { fail(OVM_ERR_SHAPE, "lin: unaligned fp32 operand"); return; }
-    chk(launch_gemm_small_ex(A, A2, lda, M, W.K, W.hi, W.lo, W.N, W.Kpad, W.bias, act, R, ldr, C, ldc, g->npass, pl->gemm_ws, pl->gemm_ws_cap, s),
+    chk(launch_gemm_small_ex(A, A2, lda, M, W.K, W.hi, W.lo, W.N, W.Kpad, W.bias, act, R, ldr, C, ldc, g->npass, ws, ws_cap, s),
         "lin");
   }
   void ln(const float* x, int M, int D, const Ln& w, float eps, const float* res, float* y, SplitBuf* sp = nullptr) {
@@ -586,16 +620,20 @@ void deform(Run& r, const MsdaW& w, const float* value, int ldv, const float* ow
 }
 
 int forward_impl(Run& r) {
-  OvmGdino* g = r.g; Plan* pl = r.pl; hipStream_t s = r.s;
+  OvmGdino* g = r.g; Plan* pl = r.pl;
+  r.init_streams();
+  const hipStream_t s = r.s_main;                        // image branch / joined sections; text-branch launches use r.s
   const OvmGdinoConfig& c = g->cfg;
   const int D = c.d_model, T = pl->T, S = pl->S, Q = c.num_queries;
   const float eps = c.eps;
   const bool dry = r.dry;
 
   // =============================== text: BERT + projection ===============================
+  // (text branch: runs beside the Swin backbone and the neck below, joined before the encoder)
   const int BD = g->bertD, BH = c.bert_heads;
   float* tx = r.f32((size_t)T * BD);
-  if (r.go()) r.chk(launch_bert_embed(g->word, g->posemb, g->typemb, pl->d_ids, pl->d_pids, T, BD, g->emb_ln.g, g->emb_ln.b, 1e-12f, tx, s), "bert_embed");
+  r.fork(); r.on_text();
+  if (r.go()) r.chk(launch_bert_embed(g->word, g->posemb, g->typemb, pl->d_ids, pl->d_pids, T, BD, g->emb_ln.g, g->emb_ln.b, 1e-12f, tx, r.s), "bert_embed");
   {
     float* qkv = r.f32((size_t)T * 3 * BD);
     float* ctx = r.f32((size_t)T * BD);
@@ -616,6 +654,7 @@ int forward_impl(Run& r) {
   r.lin(tx, nullptr, BD, T, g->text_proj, 0, nullptr, 0, text0, D);
   r.tap("text_features", text0, (int64_t)T * D);
   float* text = r.f32((size_t)T * D);                     // encoder output (the input above stays intact for the debug tap)
+  r.on_image();
 
   // =============================== image: Swin backbone ===============================
   const int ws = c.swin_window, ws2 = ws * ws;
@@ -730,6 +769,7 @@ int forward_impl(Run& r) {
   }
 
   // =============================== encoder ===============================
+  r.join();                                               // text features and image features meet in the fusion layers
   const int HF = c.heads / 2, E = c.ffn_dim / 2, dhf = E / HF;
   {
     const size_t mk = r.mark();
@@ -768,7 +808,9 @@ int forward_impl(Run& r) {
         b.cv_hi = cv.hi; b.cv_lo = cv.lo; b.ldcv = cv.ld; b.ct = ct; b.sc = sc; b.stat = stat; b.part = part; b.chunk = chunk; b.nchunk = nchunk;
         r.chk(launch_biattn(b, s), "biattn"); r.launches += 3;
       }
-      { GemmParams q = r.gp(cv, S, ly.ov); q.C = vis; q.ldc = D; q.R = v; q.ldr = D; r.gemm(q, EPI_STORE); }
+      // the two halves of the layer from here on touch disjoint buffers: text side (ot, text enhancer -> text) on the text
+      // branch, image side (ov, deformable self-attention, FFN -> vis) on the main one; joined at the end of the layer
+      r.fork(); r.on_text();
       r.lin(ct, nullptr, E, T, ly.ot, 0, t, D, text2, D);
       // ---- text enhancer
       r.lin(text2, pl->text_pos, D, T, ly.te.qk, 0, nullptr, 0, tqk, 2 * D);
@@ -779,6 +821,8 @@ int forward_impl(Run& r) {
       r.lin(text2, nullptr, D, T, ly.te_fc1, 1, nullptr, 0, tff, ly.te_fc1.N);
       r.lin(tff, nullptr, ly.te_fc1.N, T, ly.te_fc2, 0, text2, D, t, D);
       r.ln(t, T, D, ly.te_ln2, eps, nullptr, text);
+      r.on_image();
+      { GemmParams q = r.gp(cv, S, ly.ov); q.C = vis; q.ldc = D; q.R = v; q.ldr = D; r.gemm(q, EPI_STORE); }
       // ---- deformable self-attention over the image tokens
       {
         RowOpParams p; memset(&p, 0, sizeof(p));
@@ -794,6 +838,7 @@ int forward_impl(Run& r) {
       { GemmParams q = r.gp(vsp, S, ly.de_fc1); q.Ohi = ff.hi; q.Olo = ff.lo; q.ldo = ff.ld; q.relu = 1; r.gemm(q, EPI_STORE); }
       { GemmParams q = r.gp(ff, S, ly.de_fc2); q.C = pre; q.ldc = D; q.R = v; q.ldr = D; r.gemm(q, EPI_STORE); }
       r.ln(pre, S, D, ly.de_ln2, eps, nullptr, vis);
+      r.join();
     }
     r.release(mk);
   }
@@ -931,6 +976,15 @@ int ovm_gdino_create(const OvmGdinoConfig* cfg, const OvmTensor* weights, int32_
   *out = g;                                      // returned even on failure so that ovm_gdino_last_error can be read; destroy it
   g->cfg = *cfg; g->device = device; g->npass = cfg->precision == 1 ? 1 : 3;
   g->graphs_enabled = cfg->use_graphs;
+  g->branches = g_gdino_branches;
+  {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);         // hi = numerically lowest = highest priority
+    if (hipStreamCreateWithPriority(&g->aux, hipStreamNonBlocking, hi) != hipSuccess || hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming) != hipSuccess) {
+      g->err = "could not create the text-branch stream"; return OVM_ERR_HIP;
+    }
+  }
   const OvmGdinoConfig& c = g->cfg;
   if (c.d_model % c.heads || c.n_levels > 8 || c.n_levels < 1 || c.swin_window <= 0) { g->err = "bad GroundingDINO config"; return OVM_ERR_INVALID; }
   GCHECK(g, hipSetDevice(device));
@@ -1085,6 +1139,9 @@ int ovm_gdino_destroy(OvmGdino* g) {
   (void)hipDeviceSynchronize();
   for (Plan* p : g->plans) delete p;
   for (void* p : g->allocs) (void)hipFree(p);
+  if (g->aux) (void)hipStreamDestroy(g->aux);
+  if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
+  if (g->ev_join) (void)hipEventDestroy(g->ev_join);
   delete g;
   return OVM_OK;
 }

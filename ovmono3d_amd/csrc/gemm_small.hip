@@ -272,6 +272,11 @@ int launch_gemm_small_ex(const float* A, const float* A2, int lda, int M, int K,
     if (ksplit > g_max_ksplit) ksplit = g_max_ksplit;
     if (ksplit < 1) ksplit = 1;
   }
+  if (ws && ksplit > 1) {                                  // caller-owned workspace: as many slices as fit
+    const size_t per = (size_t)M * ((N + 3) / 4 * 4) * sizeof(float);
+    const size_t fit = per ? ws_bytes / per : 0;
+    if ((size_t)ksplit > fit) ksplit = fit >= 2 ? (int)fit : 1;
+  }
   int steps = (nk + ksplit - 1) / ksplit;
   ksplit = (nk + steps - 1) / steps;                      // no empty split
   p.ksplit = ksplit; p.kchunk = steps * 64;

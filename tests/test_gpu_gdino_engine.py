@@ -99,6 +99,34 @@ def test_engine_graph_replay_and_plans_own_their_scratch(device):
     assert torch.equal(eager.forward(im, other)[1], graphed.forward(im, other)[1])
 
 
+def test_engine_text_branch_on_its_own_stream_is_bit_identical(device):
+    """The text side of the network (BERT, then each encoder layer's text enhancer) runs on a second stream / graph branch beside
+    the image side (Swin + neck, deformable attention). Same kernels, same operands, another schedule: outputs must equal the
+    single-stream order bit for bit, eagerly and under graph replay, on repeated calls with new pixels."""
+    from ovmono3d_amd import lib
+    L = lib.load()
+    hf, _ = _small_hf_gdino()
+    sd = hf.state_dict()
+    try:
+        L.ovm_tune_set(b"gdino_branches", 0)
+        single = _engine(device, sd, SMALL, use_graphs=False)
+        L.ovm_tune_set(b"gdino_branches", 1)
+        two_eager = _engine(device, sd, SMALL, use_graphs=False)
+        two_graph = _engine(device, sd, SMALL, use_graphs=True)
+    finally:
+        L.ovm_tune_set(b"gdino_branches", 1)
+    g = torch.Generator().manual_seed(9)
+    ids = [101, 500, 1012, 600, 601, 1012, 700, 701, 702, 1012, 102]
+    for i, (h, w) in enumerate([(96, 132), (96, 132), (160, 200), (96, 132), (96, 132)]):
+        im = torch.randint(0, 256, (3, h, w), dtype=torch.uint8, generator=g).to(device)
+        a_l, a_b = single.forward(im, ids)
+        for eng in (two_eager, two_graph):
+            b_l, b_b = eng.forward(im, ids)
+            assert torch.equal(a_b, b_b) and torch.equal(a_l, b_l), (i, h, w)
+    T = len(ids)
+    assert torch.equal(single.debug("enc_text", (T, 64)), two_graph.debug("enc_text", (T, 64)))
+
+
 def test_engine_full_size_swinb_matches_hf(device):
     """The real architecture (Swin-B 384 / window 12, BERT-base, 6 + 6 layers, 900 queries) at a non-square network resolution,
     random weights; HF runs in fp32 on the same GPU. Also prints the engine's kernel launches per forward and its time."""
