@@ -187,7 +187,7 @@ def main():
     flops_launch = kf[dominant] * B
     achieved = flops_launch / (avg_ms * 1e-3) / 1e12
     # HBM-side bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass over this same command
-    # (profiles/r01/pmc_traffic_*.json documents the command and the gfx950 FETCH_SIZE correction); null if none matches
+    # (profiles/rNN/pmc_traffic_*.json documents the command and the gfx950 FETCH_SIZE correction; newest round first); null if none matches
     traffic = traffic_source = None
     for tdir in ("r02", "r01"):
         try:
@@ -201,8 +201,8 @@ def main():
                     if key and key in kn:
                         traffic = kv["traffic_bytes_per_launch"]
                         traffic_source = (f"profiles/{tdir}/pmc_traffic_f16x3_vitl14_T4097_b1.json: separate rocprofv3 --pmc FETCH_SIZE / "
-                                          f"WRITE_SIZE passes over bench.py --proposals {wl.get('proposals', 'oracle2d')} (same kernel, same "
-                                          "shapes; not collected in this run)")
+                                          f"WRITE_SIZE passes over bench.py --proposals {wl.get('proposals', 'oracle2d')} (per-launch bytes of the "
+                                          "same kernel at the same shapes, counters-only run of its own: PMC collection cannot share the timed run)")
                 if traffic is not None:
                     break
         except (OSError, KeyError, ValueError):
