@@ -49,7 +49,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16"])
-    ap.add_argument("--model", default="vitl14")
+    ap.add_argument("--model", default="vitl14", help="DINOv2 arch (vitl14 ...) or, with --tower clip, an open_clip arch (ViT-B-16)")
+    ap.add_argument("--tower", default="dinov2", choices=["dinov2", "clip"],
+                    help="clip: the CLIP ViT-B/16 image tower config (BASELINE configs[3]; a parity-test case, not the headline): "
+                         "use --model ViT-B-16 --canvas 1024 --net-res 608 --proposals oracle2d")
     ap.add_argument("--canvas", type=int, default=896)
     ap.add_argument("--net-res", type=int, default=532)
     ap.add_argument("--boxes", type=int, default=32, help="boxes per image for --proposals oracle2d")
@@ -76,12 +79,13 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
-    from common import build_cfg, oracle_params
+    from common import build_cfg, build_clip_cfg, oracle_params
     from ovmono3d_amd.modeling import build_model
-    from ovmono3d_amd.util.synth_weights import VIT_ARCH, synth_state_dict
+    from ovmono3d_amd.util.synth_weights import CLIP_ARCH, VIT_ARCH, synth_state_dict
 
-    D, L, heads = VIT_ARCH[args.model]
-    G = args.canvas // 14
+    clip = args.tower == "clip"
+    D, L, heads = CLIP_ARCH[args.model][:3] if clip else VIT_ARCH[args.model]
+    G = args.canvas // (16 if clip else 14)
     T = G * G + 1
     B = args.batch
 
@@ -119,7 +123,7 @@ def main():
         gd_hf, gd_sd = synth_gdino_model(0)
 
     def run(precision, steps, warmup, profile):
-        cfg = build_cfg(args.model, args.canvas, precision, max_batch=B, max_rois=1000 if use_gdino else max(64, args.boxes),
+        cfg = (build_clip_cfg if clip else build_cfg)(args.model, args.canvas, precision, max_batch=B, max_rois=1000 if use_gdino else max(64, args.boxes),
                         roi_heads="ROIHeads3DGDINO" if use_gdino else "ROIHeads3D",
                         extra=["MODEL.AMD.GDINO_CORUN", os.environ.get("OVM_BENCH_CORUN", "0") == "1"])
         model = build_model(cfg, device=dev)
@@ -385,7 +389,7 @@ def main():
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16x3" if args.precision == "f16x3" else "f16", "data": "synthetic",
-            "config": {"workload": f"DINOv2 {args.model} + SFP + "
+            "config": {"workload": ("CLIP image tower " if clip else "DINOv2 ") + f"{args.model} + SFP + "
                                    + ("ROIHeads3DGDINO (native GroundingDINO Swin-B/BERT-base, 900 queries, 6 categories -> NMS)" if use_gdino
                                       else f"oracle-2D boxes ({args.boxes}/img)")
                                    + f" + ROIAlign + CubeHead + decode, batch {B}/GPU, 512x512 synthetic -> network res {args.net_res} "
