@@ -70,11 +70,18 @@ typedef struct OvmConfig {
    *                         image tower (conv1 without bias, class_embedding, ln_pre, QuickGELU, LN eps 1e-5, no ln_post / proj),
    *                         patch 16, pos-embed resized with antialiased bicubic (:98-133); pyramid scales (4, 2, 1, 0.5)
    *                         -> p2..p5 at strides 4 / 8 / 16 / 32; checkpoint keys backbone.net.visual.*; prompt_depth refused
-   *                         (detectron2's SimpleFeaturePyramid.forward takes no depth: SURVEY.md 0.4). */
+   *                         (detectron2's SimpleFeaturePyramid.forward takes no depth: SURVEY.md 0.4).
+   *   OVM_TOWER_MAE    (2)  build_mae_backbone, reference cubercnn/modeling/backbone/mae.py:20-150: Hugging Face ViTMAE encoder
+   *                         (patch 16 with bias, separate query / key / value linears, erf-GELU, LN eps 1e-12, no LayerScale),
+   *                         position embeddings = fixed 2-D sin-cos table rebuilt for the canvas grid (:62-78,152-180), class token
+   *                         + its (zero) position row, tap = hidden_states[depth] i.e. `depth` blocks are run - the reference taps
+   *                         hidden_states[num_layers - 1], the state BEFORE the last block (:43-55,110-116), so depth = 11 for
+   *                         vit-mae-base; same 4-level pyramid and prompt_depth rule as CLIP; keys backbone.net.vit.embeddings.*,
+   *                         backbone.net.vit.encoder.layer.N.* */
   int32_t tower;
 } OvmConfig;
 
-enum { OVM_TOWER_DINOV2 = 0, OVM_TOWER_CLIP = 1 };
+enum { OVM_TOWER_DINOV2 = 0, OVM_TOWER_CLIP = 1, OVM_TOWER_MAE = 2 };
 
 /* One host-resident fp32 tensor of a checkpoint, named with the reference state_dict key
  * (module tree printed at reference nohup.out:563-684; loaded at reference demo/demo.py:148). */
@@ -190,6 +197,10 @@ int ovm_host_interp_pos_embed(const float* pos, int32_t M, int32_t D, int32_t G,
 /* resize_pos_embed of the CLIP tower (reference cubercnn/modeling/backbone/clip.py:98-133): F.interpolate(size=(G,G), bicubic,
  * align_corners=False, antialias=True) of the patch rows, class row kept: pos [1+M*M][D] -> out [1+G*G][D] */
 int ovm_host_resize_pos_embed_aa(const float* pos, int32_t M, int32_t D, int32_t G, float* out);
+/* get_2d_sincos_pos_embed(D, (G, G), add_cls_token=True) of the MAE tower (reference cubercnn/modeling/backbone/mae.py:152-180 over
+ * transformers' get_2d_sincos_pos_embed_from_grid): out [1+G*G][D], row 0 zero; first D/2 columns encode the x coordinate, the
+ * rest y, each as [sin | cos] over D/4 frequencies 10000^(-i/(D/4)); computed in double, stored fp32 */
+int ovm_host_sincos_pos_embed(int32_t D, int32_t G, float* out);
 /* InferenceSampler contiguous shard [begin,end) of rank (reference cubercnn/data/build.py:320) */
 int ovm_host_shard_range(int64_t n_items, int32_t rank, int32_t world, int64_t* begin, int64_t* end);
 

@@ -13,13 +13,13 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
-from . import clip_vit, heads, rpn, sfp, vit
+from . import clip_vit, heads, mae_vit, rpn, sfp, vit
 
 
 @dataclass
 class OracleParams:
     model_name: str = "vitl14"
-    tower: str = "dinov2"                                           # 'dinov2' (build_dino_backbone) | 'clip' (build_clip_backbone)
+    tower: str = "dinov2"                                           # 'dinov2' | 'clip' | 'mae' (build_*_backbone); for 'mae' depth = num_layers
     embed_dim: int = 1024
     depth: int = 24
     heads: int = 16
@@ -67,6 +67,9 @@ def backbone(sd, images: torch.Tensor, P: OracleParams, prompt_depth=None) -> Di
         # detectron2's SimpleFeaturePyramid.forward(x) has no depth argument: the fork's rcnn3d.py:97 call with one raises
         assert prompt_depth is None, "the CLIP backbone takes no prompt_depth (SURVEY.md 0.4)"
         return sfp.sfp4_forward(sd, clip_vit.clip_backbone_forward(sd, images, P.heads, P.depth))
+    if P.tower == "mae":
+        assert prompt_depth is None, "the MAE backbone takes no prompt_depth (SURVEY.md 0.4)"
+        return sfp.sfp4_forward(sd, mae_vit.mae_backbone_forward(sd, images, P.heads, P.depth))
     dense = vit.dino_backbone_forward(sd, images, P.heads, P.depth, prompt_depth, P.use_depth_fusion)
     return sfp.sfp_forward(sd, dense)
 

@@ -236,6 +236,9 @@ def get_cfg_defaults(cfg: CfgNode) -> CfgNode:
     # CLIP image tower behind the same pyramid and heads (reference config.py:100-105, backbone/clip.py; MODEL.BACKBONE.NAME
     # 'build_clip_backbone'); ARCH names follow open_clip
     cfg.MODEL.CLIP = CfgNode(dict(ARCH="ViT-B-16", CHECKPOINT="openai", OUTPUT="dense", LAYER=-1, RETURN_MULTILAYER=False))
+    # MAE ViT encoder (reference config.py:94-98, backbone/mae.py; 'build_mae_backbone'); CHECKPOINT names a Hugging Face repo there,
+    # here it selects the architecture table entry (util/synth_weights.MAE_ARCH)
+    cfg.MODEL.MAE = CfgNode(dict(CHECKPOINT="facebook/vit-mae-base", OUTPUT="dense", LAYER=-1, RETURN_MULTILAYER=False))
 
     H = CfgNode()
     H.NAME = "CubeHead"

@@ -497,20 +497,40 @@ int ovm_host_resize_pos_embed_aa(const float* pos, int32_t M, int32_t D, int32_t
   return OVM_OK;
 }
 
+int ovm_host_sincos_pos_embed(int32_t D, int32_t G, float* out) {
+  if (D <= 0 || D % 4 != 0 || G <= 0) return OVM_ERR_INVALID;
+  const int Q = D / 4;                                       // frequencies per (coordinate, sin / cos)
+  std::vector<double> omega(Q);
+  for (int i = 0; i < Q; ++i) omega[i] = 1.0 / pow(10000.0, (double)i / (double)Q);
+  for (int d = 0; d < D; ++d) out[d] = 0.f;
+  for (int y = 0; y < G; ++y)
+    for (int x = 0; x < G; ++x) {
+      float* o = out + (size_t)(1 + y * G + x) * D;
+      // meshgrid(grid_w, grid_h): "grid[0]" is the x coordinate and feeds the FIRST half (named emb_h upstream)
+      for (int i = 0; i < Q; ++i) {
+        const double ax = (double)x * omega[i], ay = (double)y * omega[i];
+        o[i] = (float)sin(ax); o[Q + i] = (float)cos(ax);
+        o[2 * Q + i] = (float)sin(ay); o[3 * Q + i] = (float)cos(ay);
+      }
+    }
+  return OVM_OK;
+}
+
 int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights, int32_t device, OvmHandle** out) {
   if (!cfg || !out) return OVM_ERR_INVALID;
   OvmHandle* h = new OvmHandle();
   *out = h;
   h->cfg = *cfg; h->device = device;
   const OvmConfig& c = h->cfg;
-  const bool clip = c.tower == OVM_TOWER_CLIP;
-  if (c.tower != OVM_TOWER_DINOV2 && !clip) { h->err = "invalid config (tower)"; return OVM_ERR_INVALID; }
-  h->patch = clip ? 16 : 14; h->nlev = clip ? 4 : 3;
-  h->ln_eps = clip ? 1e-5f : 1e-6f; h->mlp_act = clip ? 3 : 0;
-  h->Kpe = clip ? 768 : 640;
+  const bool clip = c.tower == OVM_TOWER_CLIP, mae = c.tower == OVM_TOWER_MAE;
+  const bool p16 = clip || mae;                           // patch-16 towers behind the 4-level pyramid
+  if (c.tower != OVM_TOWER_DINOV2 && !p16) { h->err = "invalid config (tower)"; return OVM_ERR_INVALID; }
+  h->patch = p16 ? 16 : 14; h->nlev = p16 ? 4 : 3;
+  h->ln_eps = clip ? 1e-5f : (mae ? 1e-12f : 1e-6f); h->mlp_act = clip ? 3 : 0;
+  h->Kpe = p16 ? 768 : 640;
   // the scale-4 stage needs D/4 channels in 64-wide k-steps
   if (c.canvas % h->patch != 0 || c.embed_dim % 128 != 0 || c.embed_dim != c.heads * 64 || (c.precision != 1 && c.precision != 3) ||
-      c.fpn_channels % 64 != 0 || c.max_batch < 1 || c.max_rois < 1 || (clip && c.embed_dim % 256 != 0)) {
+      c.fpn_channels % 64 != 0 || c.max_batch < 1 || c.max_rois < 1 || (p16 && c.embed_dim % 256 != 0)) {
     h->err = "invalid config (canvas % patch, embed_dim = heads*64 and %128 (%256 for 4-level towers), precision in {1,3}, fpn_channels %64)";
     return OVM_ERR_INVALID;
   }
@@ -524,9 +544,10 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
   int r;
   const int P = h->patch, PP = P * P;
   const std::string V = clip ? "backbone.net.visual." : "backbone.net.vit.";
+  const std::string PEW = clip ? "conv1.weight" : (mae ? "embeddings.patch_embeddings.projection.weight" : "patch_embed.proj.weight");
   // ---- patch embed: [D][3][P][P] -> [D][(py*P+px)*3 + c]; P = 14: K padded 588 -> 640
   {
-    const float* w; r = get_host(h, wm, V + (clip ? "conv1.weight" : "patch_embed.proj.weight"), (int64_t)D * 3 * PP, &w); if (r) return r;
+    const float* w; r = get_host(h, wm, V + PEW, (int64_t)D * 3 * PP, &w); if (r) return r;
     std::vector<float> v((size_t)D * 3 * PP);
     for (int o = 0; o < D; ++o)
       for (int ch = 0; ch < 3; ++ch)
@@ -541,6 +562,10 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
       r = ovm_host_resize_pos_embed_aa(pos, c.pos_grid, D, G, pi.data()); if (r) return r;
       r = upload_f32(h, wm, V + "ln_pre.weight", D, &h->lnpre_g); if (r) return r;
       r = upload_f32(h, wm, V + "ln_pre.bias", D, &h->lnpre_b); if (r) return r;
+    } else if (mae) {                                      // HF ViTMAE embeddings, position table rebuilt for this grid (mae.py:62-78)
+      r = upload_f32(h, wm, V + "embeddings.patch_embeddings.projection.bias", D, &h->pe.bias); if (r) return r;
+      r = upload_f32(h, wm, V + "embeddings.cls_token", D, &h->cls); if (r) return r;
+      r = ovm_host_sincos_pos_embed(D, G, pi.data()); if (r) return r;
     } else {
       r = upload_f32(h, wm, V + "patch_embed.proj.bias", D, &h->pe.bias); if (r) return r;
       r = upload_f32(h, wm, V + "cls_token", D, &h->cls); if (r) return r;
@@ -565,6 +590,20 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
       if ((r = pack_linear(h, wm, Pq + "mlp.c_proj", D, 4 * D, &y.fc2))) return r;
       continue;
     }
+    if (mae) {                                             // HF ViTLayer: layernorm_before, attention (q / k / v / output.dense), layernorm_after, MLP
+      const std::string Pq = V + "encoder.layer." + std::to_string(l) + ".";
+      if ((r = upload_f32(h, wm, Pq + "layernorm_before.weight", D, &y.ln1g))) return r;
+      if ((r = upload_f32(h, wm, Pq + "layernorm_before.bias", D, &y.ln1b))) return r;
+      if ((r = upload_f32(h, wm, Pq + "layernorm_after.weight", D, &y.ln2g))) return r;
+      if ((r = upload_f32(h, wm, Pq + "layernorm_after.bias", D, &y.ln2b))) return r;
+      y.ls1 = y.ls2 = nullptr;
+      const std::string A = Pq + "attention.attention.";
+      if ((r = pack_concat(h, wm, {{A + "query", D}, {A + "key", D}, {A + "value", D}}, D, &y.qkv))) return r;
+      if ((r = pack_linear(h, wm, Pq + "attention.output.dense", D, D, &y.proj))) return r;
+      if ((r = pack_linear(h, wm, Pq + "intermediate.dense", 4 * D, D, &y.fc1))) return r;
+      if ((r = pack_linear(h, wm, Pq + "output.dense", D, 4 * D, &y.fc2))) return r;
+      continue;
+    }
     const std::string P = V + "blocks." + std::to_string(l) + ".";
     if ((r = upload_f32(h, wm, P + "norm1.weight", D, &y.ln1g))) return r;
     if ((r = upload_f32(h, wm, P + "norm1.bias", D, &y.ln1b))) return r;
@@ -577,7 +616,7 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
     if ((r = pack_linear(h, wm, P + "mlp.fc1", 4 * D, D, &y.fc1))) return r;
     if ((r = pack_linear(h, wm, P + "mlp.fc2", D, 4 * D, &y.fc2))) return r;
   }
-  h->has_dfuse = !clip && c.use_depth_fusion && wm.get("backbone.net.depth_fusion.weight");
+  h->has_dfuse = !p16 && c.use_depth_fusion && wm.get("backbone.net.depth_fusion.weight");
   if (h->has_dfuse) {
     if ((r = pack_linear(h, wm, "backbone.net.depth_fusion", D, D + 1, &h->dfuse, true, D + 64))) return r;
   }
@@ -590,7 +629,7 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
     const int first = 2;                                                // int(log2(7)) = int(log2(4)) = 2
     int li = 0;
     auto sname = [&](int lvl, int idx) { return "backbone.simfp_" + std::to_string(first + lvl) + "." + std::to_string(idx); };
-    if (clip) {
+    if (p16) {
       if ((r = pack_convt(h, wm, sname(li, 0), D, D / 2, &h->convt4a))) return r;
       if ((r = upload_f32(h, wm, sname(li, 1) + ".weight", D / 2, &h->up_ln_g))) return r;
       if ((r = upload_f32(h, wm, sname(li, 1) + ".bias", D / 2, &h->up_ln_b))) return r;
@@ -647,7 +686,7 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
   }
   const int G2x = 2 * G, G4 = G / 2;
   if ((r = salloc(h, &h->CT, (size_t)B * G2x * G2x * (D / 2)))) return r;
-  if (clip) {
+  if (p16) {
     if ((r = salloc(h, &h->CT4a, (size_t)B * G2x * G2x * (D / 2)))) return r;
     if ((r = salloc(h, &h->CT4b, (size_t)B * 4 * G2x * G2x * (D / 4)))) return r;
   }

@@ -35,7 +35,7 @@ class OvmConfig(C.Structure):
     ]
 
 
-OVM_TOWER_DINOV2, OVM_TOWER_CLIP = 0, 1
+OVM_TOWER_DINOV2, OVM_TOWER_CLIP, OVM_TOWER_MAE = 0, 1, 2
 
 
 class OvmTensor(C.Structure):
@@ -61,7 +61,7 @@ class OvmGdinoConfig(C.Structure):
 
 EXPORTS = [
     "ovm_create", "ovm_destroy", "ovm_last_error", "ovm_version", "ovm_abi_sizeof", "ovm_backbone_forward", "ovm_cube_forward",
-    "ovm_rpn_box_forward", "ovm_gather_records", "ovm_gather_counts", "ovm_host_interp_pos_embed", "ovm_host_resize_pos_embed_aa", "ovm_host_shard_range",
+    "ovm_rpn_box_forward", "ovm_gather_records", "ovm_gather_counts", "ovm_host_interp_pos_embed", "ovm_host_resize_pos_embed_aa", "ovm_host_sincos_pos_embed", "ovm_host_shard_range",
     "ovm_backbone_num_levels", "ovm_backbone_level",
     "ovm_op_split_f16", "ovm_op_interleave", "ovm_op_gemm", "ovm_op_layernorm", "ovm_op_attention", "ovm_op_roi_align",
     "ovm_op_cube_decode", "ovm_op_nms", "ovm_debug_copy", "ovm_set_corun", "ovm_profile_enable", "ovm_profile_read",
@@ -104,6 +104,7 @@ def load() -> C.CDLL:
     lib.ovm_gather_counts.argtypes = [vp, i32, i32, i32, C.POINTER(i32), vp]
     lib.ovm_host_interp_pos_embed.argtypes = [vp, i32, i32, i32, vp]
     lib.ovm_host_resize_pos_embed_aa.argtypes = [vp, i32, i32, i32, vp]
+    lib.ovm_host_sincos_pos_embed.argtypes = [i32, i32, vp]
     lib.ovm_backbone_num_levels.argtypes = [vp]
     lib.ovm_backbone_level.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(f32)]
     lib.ovm_host_shard_range.argtypes = [i64, i32, i32, C.POINTER(i64), C.POINTER(i64)]

@@ -12,8 +12,8 @@ import numpy as np
 import torch
 
 from . import lib as _lib
-from .lib import OVM_REC_FLOATS, OVM_TOWER_CLIP, OVM_TOWER_DINOV2, OvmConfig, OvmImage, check
-from .util.synth_weights import CLIP_ARCH, VIT_ARCH
+from .lib import OVM_REC_FLOATS, OVM_TOWER_CLIP, OVM_TOWER_DINOV2, OVM_TOWER_MAE, OvmConfig, OvmImage, check
+from .util.synth_weights import CLIP_ARCH, MAE_ARCH, VIT_ARCH
 
 
 def config_to_native(cfg) -> OvmConfig:
@@ -39,8 +39,20 @@ def config_to_native(cfg) -> OvmConfig:
             raise ValueError("native path supports MODEL.CLIP.OUTPUT 'dense', LAYER -1, single layer")
         D, L, heads, patch, pos_grid = CLIP_ARCH[name]
         n_levels = 4
+    elif backbone == "build_mae_backbone":
+        tower = OVM_TOWER_MAE
+        name = cfg.MODEL.MAE.CHECKPOINT
+        if name not in MAE_ARCH:
+            raise ValueError(f"unsupported MODEL.MAE.CHECKPOINT {name!r} (known: {sorted(MAE_ARCH)})")
+        if cfg.MODEL.MAE.OUTPUT != "dense" or cfg.MODEL.MAE.RETURN_MULTILAYER or cfg.MODEL.MAE.LAYER != -1:
+            raise ValueError("native path supports MODEL.MAE.OUTPUT 'dense', LAYER -1, single layer")
+        D, L, heads, patch = MAE_ARCH[name]
+        # the reference taps hidden_states[num_layers - 1] (mae.py:43-55,110-116): the state before the LAST block, so one block fewer runs
+        L = L - 1
+        pos_grid, n_levels = 0, 4
     else:
-        raise ValueError(f"MODEL.BACKBONE.NAME {backbone!r} is not on the native path (build_dino_backbone, build_clip_backbone)")
+        raise ValueError(f"MODEL.BACKBONE.NAME {backbone!r} is not on the native path (build_dino_backbone, build_clip_backbone, "
+                         "build_mae_backbone)")
     H = cfg.MODEL.ROI_CUBE_HEAD
     unsupported = []
     if H.Z_TYPE != "direct": unsupported.append("Z_TYPE")
@@ -118,11 +130,11 @@ class Engine:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self._lib = _lib.load()
         self._h = C.c_void_p()
-        self.patch = 16 if self.ncfg.tower == OVM_TOWER_CLIP else 14
+        self.patch = 14 if self.ncfg.tower == OVM_TOWER_DINOV2 else 16
         self.G = self.ncfg.canvas // self.patch
         self.C = self.ncfg.fpn_channels
         # pyramid levels, finest first: (name, side of the grid on the canvas, stride in pixels)
-        scales = (4.0, 2.0, 1.0, 0.5) if self.ncfg.tower == OVM_TOWER_CLIP else (2.0, 1.0, 0.5)
+        scales = (2.0, 1.0, 0.5) if self.ncfg.tower == OVM_TOWER_DINOV2 else (4.0, 2.0, 1.0, 0.5)
         self.levels = [(f"p{2 + i}", int(self.G * sc), self.patch / sc) for i, sc in enumerate(scales)]      # G odd: MaxPool2 floors
 
     # ---- lifecycle ---------------------------------------------------------------------------

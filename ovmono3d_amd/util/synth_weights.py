@@ -39,6 +39,13 @@ CLIP_ARCH = {
 }
 
 
+MAE_ARCH = {
+    # Hugging Face checkpoint: (hidden size, layers, heads, patch)   -- reference backbone/mae.py:22 (facebook/vit-mae-base), ViTMAEConfig
+    "facebook/vit-mae-base": (768, 12, 12, 16),
+    "test/vit-mae-test": (256, 3, 4, 16),     # tiny (not a published checkpoint)
+}
+
+
 def _lin(g, out_f, in_f, std=None, bias_std=0.02):
     std = (1.0 / math.sqrt(in_f)) if std is None else std
     w = torch.randn(out_f, in_f, generator=g) * std
@@ -52,6 +59,8 @@ def synth_state_dict(model_name: str = "vitl14", num_classes: int = 50, fpn_chan
                      num_anchors: int = 3) -> Dict[str, torch.Tensor]:
     if model_name in CLIP_ARCH:
         return synth_clip_state_dict(model_name, num_classes, fpn_channels, fc_dim, pooler_res, seed, num_anchors)
+    if model_name in MAE_ARCH:
+        return synth_mae_state_dict(model_name, num_classes, fpn_channels, fc_dim, pooler_res, seed, num_anchors)
     D, L, _ = VIT_ARCH[model_name]
     g = torch.Generator().manual_seed(seed)
     sd: Dict[str, torch.Tensor] = {}
@@ -184,7 +193,14 @@ def synth_clip_state_dict(arch: str = "ViT-B-16", num_classes: int = 50, fpn_cha
     sd[V + "ln_post.weight"] = torch.ones(D)
     sd[V + "ln_post.bias"] = torch.zeros(D)
     sd[V + "proj"] = torch.randn(D, 512, generator=g) * 0.02
+    _synth_neck4(sd, g, D, fpn_channels)
     C = fpn_channels
+    _synth_heads(sd, g, C, num_classes, fc_dim, pooler_res, num_anchors)
+    return sd
+
+
+def _synth_neck4(sd, g, D, C):
+    """detectron2 SimpleFeaturePyramid with scale factors (4, 2, 1, 0.5): backbone.simfp_2 .. simfp_5."""
     conv = lambda cout, cin, k, std=None: _conv(g, cout, cin, k, std)
     ln = lambda prefix: _ln(sd, g, prefix, C)
     # p2 (scale 4): ConvT(D->D/2) . LN(D/2) . GELU . ConvT(D/2->D/4) . 1x1+LN . 3x3+LN
@@ -215,5 +231,33 @@ def synth_clip_state_dict(arch: str = "ViT-B-16", num_classes: int = 50, fpn_cha
     ln("backbone.simfp_5.1.norm")
     sd["backbone.simfp_5.2.weight"] = conv(C, C, 3)
     ln("backbone.simfp_5.2.norm")
-    _synth_heads(sd, g, C, num_classes, fc_dim, pooler_res, num_anchors)
+
+
+def synth_mae_state_dict(checkpoint: str = "facebook/vit-mae-base", num_classes: int = 50, fpn_channels: int = 256, fc_dim: int = 1024,
+                         pooler_res: int = 7, seed: int = 0, num_anchors: int = 3) -> Dict[str, torch.Tensor]:
+    """Random-init checkpoint with the key tree of the reference's MAE variant: ``backbone.net.vit.*`` is Hugging Face's ViTMAEModel
+    (``ViTMAEForPreTraining.from_pretrained(...).vit``, reference backbone/mae.py:27), then the 4-level pyramid and the heads. The stored
+    position table is the 224-pixel one; the reference rebuilds it for the canvas (:62-78), so its values never matter."""
+    D, L, _, P = MAE_ARCH[checkpoint]
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    V = "backbone.net.vit."
+    sd[V + "embeddings.cls_token"] = torch.randn(1, 1, D, generator=g) * 0.02
+    sd[V + "embeddings.position_embeddings"] = torch.zeros(1, 1 + 14 * 14, D)
+    sd[V + "embeddings.patch_embeddings.projection.weight"] = torch.randn(D, 3, P, P, generator=g) * (1.0 / math.sqrt(3.0 * P * P))
+    sd[V + "embeddings.patch_embeddings.projection.bias"] = torch.randn(D, generator=g) * 0.02
+    for i in range(L):
+        B = V + f"encoder.layer.{i}."
+        for n in ("layernorm_before", "layernorm_after"):
+            sd[B + n + ".weight"] = 0.5 + torch.rand(D, generator=g)
+            sd[B + n + ".bias"] = torch.randn(D, generator=g) * 0.05
+        for n in ("query", "key", "value"):
+            sd[B + f"attention.attention.{n}.weight"], sd[B + f"attention.attention.{n}.bias"] = _lin(g, D, D, std=2.0 / math.sqrt(D))
+        sd[B + "attention.output.dense.weight"], sd[B + "attention.output.dense.bias"] = _lin(g, D, D, std=0.5 / math.sqrt(D))
+        sd[B + "intermediate.dense.weight"], sd[B + "intermediate.dense.bias"] = _lin(g, 4 * D, D)
+        sd[B + "output.dense.weight"], sd[B + "output.dense.bias"] = _lin(g, D, 4 * D, std=0.5 / math.sqrt(4 * D))
+    sd[V + "layernorm.weight"] = torch.ones(D)
+    sd[V + "layernorm.bias"] = torch.zeros(D)
+    _synth_neck4(sd, g, D, fpn_channels)
+    _synth_heads(sd, g, fpn_channels, num_classes, fc_dim, pooler_res, num_anchors)
     return sd

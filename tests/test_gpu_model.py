@@ -8,7 +8,7 @@ oracle is the fp32 restatement in oracle/."""
 import pytest
 import torch
 
-from common import assert_close, build_cfg, build_clip_cfg, oracle_params, synth_inputs
+from common import assert_close, build_cfg, build_clip_cfg, build_mae_cfg, oracle_params, synth_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -19,7 +19,8 @@ FIELDS = ("pred_boxes", "scores", "pred_bbox3D", "pred_center_cam", "pred_center
 def _build(cfg, seed=1):
     from ovmono3d_amd.modeling import build_model
     from ovmono3d_amd.util.synth_weights import synth_state_dict
-    name = cfg.MODEL.CLIP.ARCH if cfg.MODEL.BACKBONE.NAME == "build_clip_backbone" else cfg.MODEL.DINO.MODEL_NAME
+    name = {"build_clip_backbone": cfg.MODEL.CLIP.ARCH, "build_mae_backbone": cfg.MODEL.MAE.CHECKPOINT}.get(cfg.MODEL.BACKBONE.NAME,
+                                                                                                           cfg.MODEL.DINO.MODEL_NAME)
     sd = synth_state_dict(name, num_classes=cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=seed)
     model = build_model(cfg)
     model.load_state_dict(sd)
@@ -247,4 +248,43 @@ def test_clip_vitb16_canvas1024_config4_size(device):
     for k in ("p2", "p3", "p4", "p5"):
         e = assert_close(feats[k], aux["features"][k], 1e-3, k)
         print(f"CLIP ViT-B/16 @1024 {k}: scale-relative error {e:.2e}")
+    _compare(out, ref)
+
+
+# ------------------------------------------------------------------------------------------ MAE tower ("next" row 3 analogue)
+def test_mae_tower_tiny_and_vitb16_canvas1024(device):
+    """build_mae_backbone: Hugging Face ViTMAE encoder keys (separate q / k / v linears, LN eps 1e-12, erf-GELU), 2-D sin-cos position
+    table built on the host for the canvas grid, tap = the state before the last block (reference backbone/mae.py:43-118), behind
+    the 4-level pyramid and heads - against the CPU oracle: a tiny tower (two image shapes, given boxes, then the RPN route) and
+    facebook/vit-mae-base's architecture at canvas 1024."""
+    from oracle.pipeline import inference
+    cfg = build_mae_cfg("test/vit-mae-test", 256, "f16x3", max_batch=2)
+    model, sd = _build(cfg, seed=6)
+    inputs = synth_inputs(2, hw=((160, 224), (256, 192)), n_boxes=12, seed=41)
+    out = model(inputs)
+    ref, aux = inference(sd, inputs, oracle_params(cfg), return_aux=True)
+    model.backbone.export_features = True
+    feats = model.backbone(model.preprocess_image(inputs))
+    for k in ("p2", "p3", "p4", "p5"):
+        assert_close(feats[k], aux["features"][k], 2e-4, k)
+    model.backbone.export_features = False
+    _compare(out, ref)
+    inputs2 = synth_inputs(2, hw=((192, 256), (256, 256)), n_boxes=0, seed=43, oracle2d=False)
+    out2 = model(inputs2)
+    assert len(out2[0]["instances"]) > 0
+    _compare(out2, inference(sd, inputs2, oracle_params(cfg)))
+    with pytest.raises(TypeError):
+        model(synth_inputs(1, hw=((160, 224),), n_boxes=2, seed=1), prompt_depth=torch.zeros(1, 1, 8, 8))
+    del model
+    cfg = build_mae_cfg("facebook/vit-mae-base", 1024, "f16x3", max_batch=1, max_rois=64)
+    model, sd = _build(cfg, seed=1)
+    inputs = synth_inputs(1, hw=((608, 800),), orig_scale=1.0, n_boxes=32, seed=14)
+    out = model(inputs)
+    torch.set_num_threads(16)
+    ref, aux = inference(sd, inputs, oracle_params(cfg), return_aux=True)
+    model.backbone.export_features = True
+    feats = model.backbone(model.preprocess_image(inputs))
+    for k in ("p2", "p3", "p4", "p5"):
+        e = assert_close(feats[k], aux["features"][k], 1e-3, k)
+        print(f"MAE ViT-B/16 @1024 {k}: scale-relative error {e:.2e}")
     _compare(out, ref)

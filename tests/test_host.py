@@ -40,8 +40,11 @@ def test_config_to_native_validation():
     assert k.use_depth_fusion == 0
     with pytest.raises(ValueError):
         config_to_native(build_clip_cfg("ViT-B-16", 1000))             # not a multiple of 16
+    from common import build_mae_cfg
+    m = config_to_native(build_mae_cfg("facebook/vit-mae-base", 1024))
+    assert (m.tower, m.embed_dim, m.depth, m.heads, m.pooler_max_level) == (2, 768, 11, 12, 5)      # 11 of the 12 blocks run (mae.py:43-55)
     with pytest.raises(ValueError):
-        config_to_native(build_cfg(extra=["MODEL.BACKBONE.NAME", "build_mae_backbone"]))
+        config_to_native(build_cfg(extra=["MODEL.BACKBONE.NAME", "build_sam_backbone"]))
     with pytest.raises(ValueError):
         config_to_native(build_cfg("vitl14", 900))                    # not a multiple of 14
     with pytest.raises(ValueError):

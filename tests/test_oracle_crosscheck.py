@@ -266,3 +266,59 @@ def test_sfp4_stage_shapes_and_scale4_branch():
         y = F.layer_norm(c1(y).permute(0, 2, 3, 1), (64,), sd["backbone.simfp_2.4.norm.weight"], sd["backbone.simfp_2.4.norm.bias"], 1e-6).permute(0, 3, 1, 2)
         y = F.layer_norm(c3(y).permute(0, 2, 3, 1), (64,), sd["backbone.simfp_2.5.norm.weight"], sd["backbone.simfp_2.5.norm.bias"], 1e-6).permute(0, 3, 1, 2)
     assert float((out["p2"] - y).abs().max()) < 1e-4
+
+
+def test_mae_tower_matches_hf_vitmae_encoder_and_sincos_table():
+    """oracle/mae_vit.py against Hugging Face's ViTMAEModel: the 2-D sin-cos position table (x half first - the layout the
+    pretrained weights rely on) against the table the HF model initialises itself with, and the reference's own recipe
+    (embeddings without masking -> encoder with output_hidden_states -> hidden_states[num_layers - 1]) with the same weights."""
+    from transformers import ViTMAEConfig, ViTMAEModel
+    from oracle import mae_vit
+    from ovmono3d_amd import lib
+    from ovmono3d_amd.util.synth_weights import MAE_ARCH, synth_mae_state_dict
+    name = "test/vit-mae-test"
+    D, L, heads, patch = MAE_ARCH[name]
+    grid = 10
+    sd = synth_mae_state_dict(name, seed=7)
+    cfg = ViTMAEConfig(hidden_size=D, num_hidden_layers=L, num_attention_heads=heads, intermediate_size=4 * D, image_size=grid * patch,
+                       patch_size=patch, mask_ratio=0.0, layer_norm_eps=1e-12, hidden_act="gelu", attn_implementation="eager")
+    torch.manual_seed(0)
+    m = ViTMAEModel(cfg).eval()
+    table = torch.from_numpy(mae_vit.sincos_2d(D, grid, grid)).float()
+    from transformers.models.vit_mae import modeling_vit_mae as hf_mae
+    if hasattr(hf_mae, "build_2d_sinusoidal_position_embedding"):             # transformers 5.x: canonical [h | w] halves, which its
+        t5 = hf_mae.build_2d_sinusoidal_position_embedding(height=grid, width=grid, embed_dim=D, cls_token=True)   # embeddings rotate back
+        t5 = torch.cat([t5[..., D // 2:], t5[..., :D // 2]], dim=-1).reshape(-1, D)
+        assert float((t5 - table).abs().max()) < 1e-6
+    host = np.empty((1 + grid * grid, D), np.float32)
+    assert lib.load().ovm_host_sincos_pos_embed(D, grid, host.ctypes.data) == 0
+    assert np.abs(host - table.numpy()).max() < 1e-6 and not host[0].any()
+    rect = mae_vit.sincos_2d(D, 3, 5)                                          # non-square grid: x varies fastest
+    assert rect.shape == (16, D) and np.allclose(rect[1 + 1, :D // 2], rect[1 + 5 + 1, :D // 2]) and not np.allclose(rect[2], rect[3])
+    hf = {k[len("backbone.net.vit."):]: v for k, v in sd.items() if k.startswith("backbone.net.vit.")}
+    hf["embeddings.position_embeddings"] = table[None]
+    if hasattr(m, "layers"):                                                   # transformers 5.x renamed the 4.46 parameter tree the checkpoint uses
+        ren = (("encoder.layer.", "layers."), (".attention.attention.query.", ".attention.q_proj."), (".attention.attention.key.", ".attention.k_proj."),
+               (".attention.attention.value.", ".attention.v_proj."), (".attention.output.dense.", ".attention.o_proj."),
+               (".intermediate.dense.", ".mlp.fc1."), (".output.dense.", ".mlp.fc2."))
+        def new_name(k):
+            for a, b in ren:
+                k = k.replace(a, b)
+            return k
+        hf = {new_name(k): v for k, v in hf.items()}
+    missing, unexpected = m.load_state_dict(hf, strict=False)
+    assert not unexpected and not [k for k in missing if "position_ids" not in k], (missing, unexpected)
+    x = torch.randn(2, 3, grid * patch, grid * patch, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        emb = m.embeddings.patch_embeddings(x) + m.embeddings.position_embeddings[:, 1:, :]            # mae.py:80-95, no masking
+        cls = (m.embeddings.cls_token + m.embeddings.position_embeddings[:, :1, :]).expand(2, -1, -1)
+        h = torch.cat((cls, emb), dim=1)
+        states = [h]
+        for layer in (m.layers if hasattr(m, "layers") else m.encoder.layer):    # = encoder(..., output_hidden_states=True).hidden_states
+            o = layer(h)
+            h = o[0] if isinstance(o, (tuple, list)) else o
+            states.append(h)
+        ref = states[L - 1][:, 1:].reshape(2, grid, grid, D).permute(0, 3, 1, 2)
+    got = mae_vit.mae_backbone_forward(sd, x, heads, L)
+    assert got.shape == ref.shape and float((got - ref).abs().max() / ref.abs().max()) < 2e-5
+    assert float((got - states[L][:, 1:].reshape(2, grid, grid, D).permute(0, 3, 1, 2)).abs().max()) > 1e-3   # NOT the last block's output
