@@ -80,6 +80,13 @@ def main():
     dev = torch.device("cuda", dev_index)
 
     from common import build_cfg, build_clip_cfg, oracle_params
+    # experiment knobs of libovm3d (ovm_tune_set), e.g. OVM_TUNE=gdino_branches=0 - never set by the driver's runs
+    from ovmono3d_amd import lib as _ovm_lib
+    for kv in os.environ.get("OVM_TUNE", "").split(","):
+        if "=" in kv:
+            k, v = kv.split("=")
+            if _ovm_lib.load().ovm_tune_set(k.encode(), int(v)) != 0:
+                raise SystemExit(f"OVM_TUNE: unknown key {k!r}")
     from ovmono3d_amd.modeling import build_model
     from ovmono3d_amd.util.synth_weights import CLIP_ARCH, VIT_ARCH, synth_state_dict
 

@@ -48,6 +48,4 @@ def timed(f_main, f_side):
 print("vit alone", timed(vit, None))
 print("gd alone ", timed(None, gd))
 print("together ", timed(vit, gd))
-model.engine.set_corun(True)
-print("together, corun attention", timed(vit, gd))
-model.engine.set_corun(False)
+print("together again", timed(vit, gd))

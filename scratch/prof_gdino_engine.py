@@ -6,6 +6,10 @@ from ovmono3d_amd.gdino.detector import HashTokenizer
 from ovmono3d_amd.gdino.engine import GdinoEngine
 from ovmono3d_amd.util.synth_gdino import synth_gdino_model
 dev = torch.device("cuda:0")
+from ovmono3d_amd import lib as _lib
+for kv in os.environ.get("OVM_TUNE", "").split(","):
+    if "=" in kv:
+        k, v = kv.split("="); assert _lib.load().ovm_tune_set(k.encode(), int(v)) == 0, kv
 _, sd = synth_gdino_model(0)
 H = int(os.environ.get("GD_H", 532)); W = int(os.environ.get("GD_W", 532))
 eng = GdinoEngine(dev, sd, pixel_mean=[123.675, 116.28, 103.53], pixel_std=[58.395, 57.12, 57.375], use_graphs=os.environ.get("GD_GRAPH", "1") == "1")
