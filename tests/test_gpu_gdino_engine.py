@@ -172,11 +172,12 @@ def test_engine_full_size_swinb_matches_hf(device):
           f"{eng.launches()} kernel launches per forward")
 
 
-def test_ovm_infer_one_call_equals_staged_path(device):
+@pytest.mark.parametrize("tower", ["dinov2", "clip"])
+def test_ovm_infer_one_call_equals_staged_path(device, tower):
     """ovm_infer (the whole text-prompted path of one image behind ONE C-ABI call - backbone, GroundingDINO engine on
     an internal side stream, output glue, cube head, postprocess) against the same stages sequenced by the Python host
     (ROIHeads3DGDINO.prefetch / forward): identical records. Replaces reference rcnn3d.py:79-117 with category_list."""
-    from common import build_cfg, synth_inputs
+    from common import build_cfg, build_clip_cfg, synth_inputs
     from ovmono3d_amd.gdino.detector import HashTokenizer, NativeGroundingDino
     from ovmono3d_amd.gdino.model import GDinoConfig
     from ovmono3d_amd.modeling import build_model
@@ -186,10 +187,14 @@ def test_ovm_infer_one_call_equals_staged_path(device):
     class Tok(HashTokenizer):
         def _id(self, w):
             return super()._id(w) % 1900 + 50 if w not in (".", "?") else super()._id(w)
-    sd = synth_state_dict("vittest14", seed=3)
+    sd = synth_state_dict("vittest14" if tower == "dinov2" else "ViT-test-16", seed=3)
     outs = []
     for fused in (True, False):
-        cfg = build_cfg("vittest14", 280, "f16x3", max_batch=1, max_rois=64, roi_heads="ROIHeads3DGDINO", extra=["MODEL.AMD.FUSED_INFER", fused])
+        if tower == "dinov2":
+            cfg = build_cfg("vittest14", 280, "f16x3", max_batch=1, max_rois=64, roi_heads="ROIHeads3DGDINO", extra=["MODEL.AMD.FUSED_INFER", fused])
+        else:                                                    # the 4-level towers go through the same one-call path
+            cfg = build_clip_cfg("ViT-test-16", 288, "f16x3", max_batch=1, max_rois=64, roi_heads="ROIHeads3DGDINO",
+                                 extra=["MODEL.AMD.FUSED_INFER", fused])
         model = build_model(cfg, device=device)
         model.load_state_dict(sd)
         model.roi_heads.detector = NativeGroundingDino(device, hf.state_dict(), Tok(), cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD,

@@ -97,7 +97,9 @@ def category_map_for(cfg, mode, gt, category_meta=None):
     (the rule of datasets.py:294-320 - for Objectron_test this IS the Objectron map: ids 11,14..21 -> 0..8)."""
     if category_meta:
         return CategoryMap.from_meta(category_meta)
-    names = cfg.DATASETS.CATEGORY_NAMES_NOVEL if mode == "novel" else cfg.DATASETS.CATEGORY_NAMES_BASE
+    # the evaluated names of the mode; an empty list means "every category of the file" and Omni3DGroundTruth has written that
+    # list back into the settings (datasets.py:218-226)
+    names = list(gt.filter_settings["category_names"]) if gt.filter_settings else [c["name"] for c in gt.all_categories]
     known = {c["name"] for c in gt.all_categories}
     return CategoryMap.from_names([n for n in names if n in known], gt.all_categories)
 
