@@ -77,11 +77,17 @@ typedef struct OvmConfig {
    *                         + its (zero) position row, tap = hidden_states[depth] i.e. `depth` blocks are run - the reference taps
    *                         hidden_states[num_layers - 1], the state BEFORE the last block (:43-55,110-116), so depth = 11 for
    *                         vit-mae-base; same 4-level pyramid and prompt_depth rule as CLIP; keys backbone.net.vit.embeddings.*,
-   *                         backbone.net.vit.encoder.layer.N.* */
+   *                         backbone.net.vit.encoder.layer.N.*
+   *   OVM_TOWER_MIDAS  (3)  build_midas_backbone, reference cubercnn/modeling/backbone/midas_final.py:19-95: the ViT-L/16 of MiDaS
+   *                         DPT_Large (timm vit_large_patch16_384: patch 16 with bias, class token, plain pre-norm blocks without
+   *                         LayerScale, erf-GELU, LN eps 1e-6, norm_pre = identity, no final norm), position table of the 24 x 24
+   *                         grid resized with the CLIP tower's antialiased bicubic (:64-66); checkpoint keys backbone.net.vit.*
+   *                         in timm's naming (cls_token, pos_embed, patch_embed.proj, blocks.N.{norm1,attn.qkv,attn.proj,norm2,
+   *                         mlp.fc1,mlp.fc2}); same 4-level pyramid and prompt_depth rule as CLIP */
   int32_t tower;
 } OvmConfig;
 
-enum { OVM_TOWER_DINOV2 = 0, OVM_TOWER_CLIP = 1, OVM_TOWER_MAE = 2 };
+enum { OVM_TOWER_DINOV2 = 0, OVM_TOWER_CLIP = 1, OVM_TOWER_MAE = 2, OVM_TOWER_MIDAS = 3 };
 
 /* One host-resident fp32 tensor of a checkpoint, named with the reference state_dict key
  * (module tree printed at reference nohup.out:563-684; loaded at reference demo/demo.py:148). */

@@ -13,7 +13,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
-from . import clip_vit, heads, mae_vit, rpn, sfp, vit
+from . import clip_vit, heads, mae_vit, midas_vit, rpn, sfp, vit
 
 
 @dataclass
@@ -67,6 +67,9 @@ def backbone(sd, images: torch.Tensor, P: OracleParams, prompt_depth=None) -> Di
         # detectron2's SimpleFeaturePyramid.forward(x) has no depth argument: the fork's rcnn3d.py:97 call with one raises
         assert prompt_depth is None, "the CLIP backbone takes no prompt_depth (SURVEY.md 0.4)"
         return sfp.sfp4_forward(sd, clip_vit.clip_backbone_forward(sd, images, P.heads, P.depth))
+    if P.tower == "midas":
+        assert prompt_depth is None, "the MiDaS backbone takes no prompt_depth (SURVEY.md 0.4)"
+        return sfp.sfp4_forward(sd, midas_vit.midas_backbone_forward(sd, images, P.heads, P.depth))
     if P.tower == "mae":
         assert prompt_depth is None, "the MAE backbone takes no prompt_depth (SURVEY.md 0.4)"
         return sfp.sfp4_forward(sd, mae_vit.mae_backbone_forward(sd, images, P.heads, P.depth))

@@ -239,6 +239,9 @@ def get_cfg_defaults(cfg: CfgNode) -> CfgNode:
     # MAE ViT encoder (reference config.py:94-98, backbone/mae.py; 'build_mae_backbone'); CHECKPOINT names a Hugging Face repo there,
     # here it selects the architecture table entry (util/synth_weights.MAE_ARCH)
     cfg.MODEL.MAE = CfgNode(dict(CHECKPOINT="facebook/vit-mae-base", OUTPUT="dense", LAYER=-1, RETURN_MULTILAYER=False))
+    # MiDaS DPT_Large's ViT-L/16 (reference config.py:107-110, backbone/midas_final.py; 'build_midas_backbone'). The reference hard-codes
+    # the hub model; ARCH is a native-build key that selects the architecture table entry (tests use a small one)
+    cfg.MODEL.MIDAS = CfgNode(dict(ARCH="DPT_Large", OUTPUT="dense", LAYER=-1, RETURN_MULTILAYER=False))
 
     H = CfgNode()
     H.NAME = "CubeHead"

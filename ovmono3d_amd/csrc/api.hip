@@ -522,8 +522,8 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
   *out = h;
   h->cfg = *cfg; h->device = device;
   const OvmConfig& c = h->cfg;
-  const bool clip = c.tower == OVM_TOWER_CLIP, mae = c.tower == OVM_TOWER_MAE;
-  const bool p16 = clip || mae;                           // patch-16 towers behind the 4-level pyramid
+  const bool clip = c.tower == OVM_TOWER_CLIP, mae = c.tower == OVM_TOWER_MAE, midas = c.tower == OVM_TOWER_MIDAS;
+  const bool p16 = clip || mae || midas;                  // patch-16 towers behind the 4-level pyramid
   if (c.tower != OVM_TOWER_DINOV2 && !p16) { h->err = "invalid config (tower)"; return OVM_ERR_INVALID; }
   h->patch = p16 ? 16 : 14; h->nlev = p16 ? 4 : 3;
   h->ln_eps = clip ? 1e-5f : (mae ? 1e-12f : 1e-6f); h->mlp_act = clip ? 3 : 0;
@@ -570,7 +570,9 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
       r = upload_f32(h, wm, V + "patch_embed.proj.bias", D, &h->pe.bias); if (r) return r;
       r = upload_f32(h, wm, V + "cls_token", D, &h->cls); if (r) return r;
       r = get_host(h, wm, V + "pos_embed", (int64_t)(1 + c.pos_grid * c.pos_grid) * D, &pos); if (r) return r;
-      r = ovm_host_interp_pos_embed(pos, c.pos_grid, D, G, pi.data()); if (r) return r;
+      // timm ViT of MiDaS: the reference resizes with the CLIP tower's antialiased bicubic (midas_final.py:64-66); DINOv2: hub rule
+      r = midas ? ovm_host_resize_pos_embed_aa(pos, c.pos_grid, D, G, pi.data()) : ovm_host_interp_pos_embed(pos, c.pos_grid, D, G, pi.data());
+      if (r) return r;
     }
     r = upload_vec(h, pi, &h->pos); if (r) return r;
   }
@@ -609,8 +611,11 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
     if ((r = upload_f32(h, wm, P + "norm1.bias", D, &y.ln1b))) return r;
     if ((r = upload_f32(h, wm, P + "norm2.weight", D, &y.ln2g))) return r;
     if ((r = upload_f32(h, wm, P + "norm2.bias", D, &y.ln2b))) return r;
-    if ((r = upload_f32(h, wm, P + "ls1.gamma", D, &y.ls1))) return r;
-    if ((r = upload_f32(h, wm, P + "ls2.gamma", D, &y.ls2))) return r;
+    if (midas) { y.ls1 = y.ls2 = nullptr; }                // timm Block with init_values=None: LayerScale is Identity
+    else {
+      if ((r = upload_f32(h, wm, P + "ls1.gamma", D, &y.ls1))) return r;
+      if ((r = upload_f32(h, wm, P + "ls2.gamma", D, &y.ls2))) return r;
+    }
     if ((r = pack_linear(h, wm, P + "attn.qkv", 3 * D, D, &y.qkv))) return r;
     if ((r = pack_linear(h, wm, P + "attn.proj", D, D, &y.proj))) return r;
     if ((r = pack_linear(h, wm, P + "mlp.fc1", 4 * D, D, &y.fc1))) return r;

@@ -35,7 +35,7 @@ class OvmConfig(C.Structure):
     ]
 
 
-OVM_TOWER_DINOV2, OVM_TOWER_CLIP, OVM_TOWER_MAE = 0, 1, 2
+OVM_TOWER_DINOV2, OVM_TOWER_CLIP, OVM_TOWER_MAE, OVM_TOWER_MIDAS = 0, 1, 2, 3
 
 
 class OvmTensor(C.Structure):

@@ -12,8 +12,8 @@ import numpy as np
 import torch
 
 from . import lib as _lib
-from .lib import OVM_REC_FLOATS, OVM_TOWER_CLIP, OVM_TOWER_DINOV2, OVM_TOWER_MAE, OvmConfig, OvmImage, check
-from .util.synth_weights import CLIP_ARCH, MAE_ARCH, VIT_ARCH
+from .lib import OVM_REC_FLOATS, OVM_TOWER_CLIP, OVM_TOWER_DINOV2, OVM_TOWER_MAE, OVM_TOWER_MIDAS, OvmConfig, OvmImage, check
+from .util.synth_weights import CLIP_ARCH, MAE_ARCH, MIDAS_ARCH, VIT_ARCH
 
 
 def config_to_native(cfg) -> OvmConfig:
@@ -50,9 +50,18 @@ def config_to_native(cfg) -> OvmConfig:
         # the reference taps hidden_states[num_layers - 1] (mae.py:43-55,110-116): the state before the LAST block, so one block fewer runs
         L = L - 1
         pos_grid, n_levels = 0, 4
+    elif backbone == "build_midas_backbone":
+        tower = OVM_TOWER_MIDAS
+        name = cfg.MODEL.MIDAS.ARCH
+        if name not in MIDAS_ARCH:
+            raise ValueError(f"unsupported MODEL.MIDAS.ARCH {name!r} (known: {sorted(MIDAS_ARCH)})")
+        if cfg.MODEL.MIDAS.OUTPUT != "dense" or cfg.MODEL.MIDAS.RETURN_MULTILAYER or cfg.MODEL.MIDAS.LAYER != -1:
+            raise ValueError("native path supports MODEL.MIDAS.OUTPUT 'dense', LAYER -1, single layer")
+        D, L, heads, patch, pos_grid = MIDAS_ARCH[name]
+        n_levels = 4
     else:
         raise ValueError(f"MODEL.BACKBONE.NAME {backbone!r} is not on the native path (build_dino_backbone, build_clip_backbone, "
-                         "build_mae_backbone)")
+                         "build_mae_backbone, build_midas_backbone)")
     H = cfg.MODEL.ROI_CUBE_HEAD
     unsupported = []
     if H.Z_TYPE != "direct": unsupported.append("Z_TYPE")

@@ -46,6 +46,13 @@ MAE_ARCH = {
 }
 
 
+MIDAS_ARCH = {
+    # name: (width, layers, heads, patch, pretrained position grid)   -- reference backbone/midas_final.py:23-31 (DPT_Large = timm vit_large_patch16_384)
+    "DPT_Large": (1024, 24, 16, 16, 24),
+    "DPT_test": (256, 2, 4, 16, 6),           # tiny (not a hub model)
+}
+
+
 def _lin(g, out_f, in_f, std=None, bias_std=0.02):
     std = (1.0 / math.sqrt(in_f)) if std is None else std
     w = torch.randn(out_f, in_f, generator=g) * std
@@ -61,6 +68,8 @@ def synth_state_dict(model_name: str = "vitl14", num_classes: int = 50, fpn_chan
         return synth_clip_state_dict(model_name, num_classes, fpn_channels, fc_dim, pooler_res, seed, num_anchors)
     if model_name in MAE_ARCH:
         return synth_mae_state_dict(model_name, num_classes, fpn_channels, fc_dim, pooler_res, seed, num_anchors)
+    if model_name in MIDAS_ARCH:
+        return synth_midas_state_dict(model_name, num_classes, fpn_channels, fc_dim, pooler_res, seed, num_anchors)
     D, L, _ = VIT_ARCH[model_name]
     g = torch.Generator().manual_seed(seed)
     sd: Dict[str, torch.Tensor] = {}
@@ -258,6 +267,34 @@ def synth_mae_state_dict(checkpoint: str = "facebook/vit-mae-base", num_classes:
         sd[B + "output.dense.weight"], sd[B + "output.dense.bias"] = _lin(g, D, 4 * D, std=0.5 / math.sqrt(4 * D))
     sd[V + "layernorm.weight"] = torch.ones(D)
     sd[V + "layernorm.bias"] = torch.zeros(D)
+    _synth_neck4(sd, g, D, fpn_channels)
+    _synth_heads(sd, g, fpn_channels, num_classes, fc_dim, pooler_res, num_anchors)
+    return sd
+
+
+def synth_midas_state_dict(arch: str = "DPT_Large", num_classes: int = 50, fpn_channels: int = 256, fc_dim: int = 1024, pooler_res: int = 7,
+                           seed: int = 0, num_anchors: int = 3) -> Dict[str, torch.Tensor]:
+    """Random-init checkpoint with the key tree of the reference's MiDaS variant: ``backbone.net.vit.*`` is the timm VisionTransformer MiDaS
+    keeps as ``midas.pretrained.model`` (reference backbone/midas_final.py:23-24), then the 4-level pyramid and the heads."""
+    D, L, _, P, M = MIDAS_ARCH[arch]
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    V = "backbone.net.vit."
+    sd[V + "cls_token"] = torch.randn(1, 1, D, generator=g) * 0.02
+    sd[V + "pos_embed"] = torch.randn(1, 1 + M * M, D, generator=g) * 0.02
+    sd[V + "patch_embed.proj.weight"] = torch.randn(D, 3, P, P, generator=g) * (1.0 / math.sqrt(3.0 * P * P))
+    sd[V + "patch_embed.proj.bias"] = torch.randn(D, generator=g) * 0.02
+    for i in range(L):
+        B = V + f"blocks.{i}."
+        for n in ("norm1", "norm2"):
+            sd[B + n + ".weight"] = 0.5 + torch.rand(D, generator=g)
+            sd[B + n + ".bias"] = torch.randn(D, generator=g) * 0.05
+        sd[B + "attn.qkv.weight"], sd[B + "attn.qkv.bias"] = _lin(g, 3 * D, D, std=2.0 / math.sqrt(D))
+        sd[B + "attn.proj.weight"], sd[B + "attn.proj.bias"] = _lin(g, D, D, std=0.5 / math.sqrt(D))
+        sd[B + "mlp.fc1.weight"], sd[B + "mlp.fc1.bias"] = _lin(g, 4 * D, D)
+        sd[B + "mlp.fc2.weight"], sd[B + "mlp.fc2.bias"] = _lin(g, D, 4 * D, std=0.5 / math.sqrt(4 * D))
+    sd[V + "norm.weight"] = torch.ones(D)
+    sd[V + "norm.bias"] = torch.zeros(D)
     _synth_neck4(sd, g, D, fpn_channels)
     _synth_heads(sd, g, fpn_channels, num_classes, fc_dim, pooler_res, num_anchors)
     return sd

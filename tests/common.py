@@ -12,7 +12,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from ovmono3d_amd.defaults import make_cfg  # noqa: E402
-from ovmono3d_amd.util.synth_weights import CLIP_ARCH, MAE_ARCH, VIT_ARCH, synth_state_dict  # noqa: E402
+from ovmono3d_amd.util.synth_weights import CLIP_ARCH, MAE_ARCH, MIDAS_ARCH, VIT_ARCH, synth_state_dict  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
@@ -39,12 +39,22 @@ def build_mae_cfg(checkpoint="test/vit-mae-test", canvas=256, precision="f16x3",
     return make_cfg("OVMono3D_mae_SFP.yaml", opts)
 
 
+def build_midas_cfg(arch="DPT_test", canvas=256, precision="f16x3", max_batch=2, max_rois=1000, roi_heads="ROIHeads3D", extra=()):
+    opts = ["MODEL.MIDAS.ARCH", arch, "MODEL.FPN.SQUARE_PAD", canvas, "MODEL.AMD.GEMM_PRECISION", precision,
+            "MODEL.AMD.MAX_BATCH", max_batch, "MODEL.AMD.MAX_ROIS", max_rois, "MODEL.ROI_HEADS.NAME", roi_heads]
+    opts += list(extra)
+    return make_cfg("OVMono3D_midas_SFP.yaml", opts)
+
+
 def oracle_params(cfg):
     from oracle.pipeline import OracleParams
-    if cfg.MODEL.BACKBONE.NAME in ("build_clip_backbone", "build_mae_backbone"):
+    if cfg.MODEL.BACKBONE.NAME in ("build_clip_backbone", "build_mae_backbone", "build_midas_backbone"):
         if cfg.MODEL.BACKBONE.NAME == "build_clip_backbone":
             name, tower = cfg.MODEL.CLIP.ARCH, "clip"
             D, L, h, patch, _ = CLIP_ARCH[name]
+        elif cfg.MODEL.BACKBONE.NAME == "build_midas_backbone":
+            name, tower = cfg.MODEL.MIDAS.ARCH, "midas"
+            D, L, h, patch, _ = MIDAS_ARCH[name]
         else:
             name, tower = cfg.MODEL.MAE.CHECKPOINT, "mae"
             D, L, h, patch = MAE_ARCH[name]

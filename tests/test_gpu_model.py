@@ -8,7 +8,7 @@ oracle is the fp32 restatement in oracle/."""
 import pytest
 import torch
 
-from common import assert_close, build_cfg, build_clip_cfg, build_mae_cfg, oracle_params, synth_inputs
+from common import assert_close, build_cfg, build_clip_cfg, build_mae_cfg, build_midas_cfg, oracle_params, synth_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -19,7 +19,8 @@ FIELDS = ("pred_boxes", "scores", "pred_bbox3D", "pred_center_cam", "pred_center
 def _build(cfg, seed=1):
     from ovmono3d_amd.modeling import build_model
     from ovmono3d_amd.util.synth_weights import synth_state_dict
-    name = {"build_clip_backbone": cfg.MODEL.CLIP.ARCH, "build_mae_backbone": cfg.MODEL.MAE.CHECKPOINT}.get(cfg.MODEL.BACKBONE.NAME,
+    name = {"build_clip_backbone": cfg.MODEL.CLIP.ARCH, "build_mae_backbone": cfg.MODEL.MAE.CHECKPOINT,
+            "build_midas_backbone": cfg.MODEL.MIDAS.ARCH}.get(cfg.MODEL.BACKBONE.NAME,
                                                                                                            cfg.MODEL.DINO.MODEL_NAME)
     sd = synth_state_dict(name, num_classes=cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=seed)
     model = build_model(cfg)
@@ -287,4 +288,36 @@ def test_mae_tower_tiny_and_vitb16_canvas1024(device):
     for k in ("p2", "p3", "p4", "p5"):
         e = assert_close(feats[k], aux["features"][k], 1e-3, k)
         print(f"MAE ViT-B/16 @1024 {k}: scale-relative error {e:.2e}")
+    _compare(out, ref)
+
+
+# ------------------------------------------------------------------------------------------ MiDaS tower ("next" row 3 analogue)
+def test_midas_tower_tiny_and_dpt_large_canvas1024(device):
+    """build_midas_backbone: MiDaS DPT_Large's timm ViT-L/16 keys (fused qkv, no LayerScale), position table of the 24 x 24 grid resized
+    with antialiased bicubic (up to 64 x 64 and, in the tiny tower, 6 -> 16), behind the 4-level pyramid and heads - against the
+    CPU oracle: a tiny tower on two image shapes and ViT-L/16 (24 layers, D = 1024, T = 4097) at canvas 1024."""
+    from oracle.pipeline import inference
+    cfg = build_midas_cfg("DPT_test", 256, "f16x3", max_batch=2)
+    model, sd = _build(cfg, seed=8)
+    inputs = synth_inputs(2, hw=((160, 224), (256, 192)), n_boxes=12, seed=51)
+    out = model(inputs)
+    ref, aux = inference(sd, inputs, oracle_params(cfg), return_aux=True)
+    model.backbone.export_features = True
+    feats = model.backbone(model.preprocess_image(inputs))
+    for k in ("p2", "p3", "p4", "p5"):
+        assert_close(feats[k], aux["features"][k], 2e-4, k)
+    model.backbone.export_features = False
+    _compare(out, ref)
+    del model
+    cfg = build_midas_cfg("DPT_Large", 1024, "f16x3", max_batch=1, max_rois=64)
+    model, sd = _build(cfg, seed=2)
+    inputs = synth_inputs(1, hw=((608, 800),), orig_scale=1.0, n_boxes=32, seed=15)
+    out = model(inputs)
+    torch.set_num_threads(16)
+    ref, aux = inference(sd, inputs, oracle_params(cfg), return_aux=True)
+    model.backbone.export_features = True
+    feats = model.backbone(model.preprocess_image(inputs))
+    for k in ("p2", "p3", "p4", "p5"):
+        e = assert_close(feats[k], aux["features"][k], 1e-3, k)
+        print(f"MiDaS ViT-L/16 @1024 {k}: scale-relative error {e:.2e}")
     _compare(out, ref)

@@ -43,6 +43,9 @@ def test_config_to_native_validation():
     from common import build_mae_cfg
     m = config_to_native(build_mae_cfg("facebook/vit-mae-base", 1024))
     assert (m.tower, m.embed_dim, m.depth, m.heads, m.pooler_max_level) == (2, 768, 11, 12, 5)      # 11 of the 12 blocks run (mae.py:43-55)
+    from common import build_midas_cfg
+    d = config_to_native(build_midas_cfg("DPT_Large", 1024))
+    assert (d.tower, d.embed_dim, d.depth, d.heads, d.pos_grid, d.pooler_max_level) == (3, 1024, 24, 16, 24, 5)
     with pytest.raises(ValueError):
         config_to_native(build_cfg(extra=["MODEL.BACKBONE.NAME", "build_sam_backbone"]))
     with pytest.raises(ValueError):

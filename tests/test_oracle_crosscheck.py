@@ -322,3 +322,56 @@ def test_mae_tower_matches_hf_vitmae_encoder_and_sincos_table():
     got = mae_vit.mae_backbone_forward(sd, x, heads, L)
     assert got.shape == ref.shape and float((got - ref).abs().max() / ref.abs().max()) < 2e-5
     assert float((got - states[L][:, 1:].reshape(2, grid, grid, D).permute(0, 3, 1, 2)).abs().max()) > 1e-3   # NOT the last block's output
+
+
+def test_midas_tower_block_matches_hf_vit_layer():
+    """oracle/midas_vit.py's timm-style block (fused qkv, no LayerScale, erf-GELU, LN eps 1e-6) against Hugging Face ViT layers of the
+    same architecture with the fused qkv split into query / key / value; and the whole forward's geometry (class token, resized
+    position table, last block's patch tokens, no final norm)."""
+    from transformers import ViTConfig, ViTModel
+    from oracle import clip_vit, midas_vit
+    from ovmono3d_amd.util.synth_weights import MIDAS_ARCH, synth_midas_state_dict
+    arch = "DPT_test"
+    D, L, heads, patch, M = MIDAS_ARCH[arch]
+    sd = synth_midas_state_dict(arch, seed=9)
+    m = ViTModel(ViTConfig(hidden_size=D, num_hidden_layers=L, num_attention_heads=heads, intermediate_size=4 * D, image_size=M * patch,
+                           patch_size=patch, layer_norm_eps=1e-6, hidden_act="gelu", attn_implementation="eager"), add_pooling_layer=False).eval()
+    layers = m.encoder.layer if hasattr(m, "encoder") else m.layers
+    names = dict(layers[0].named_parameters())
+    new = "attention.q_proj.weight" in names
+    with torch.no_grad():
+        for i, lyr in enumerate(layers):
+            p = f"backbone.net.vit.blocks.{i}."
+            wq, wk, wv = sd[p + "attn.qkv.weight"].chunk(3, 0)
+            bq, bk, bv = sd[p + "attn.qkv.bias"].chunk(3, 0)
+            mapping = {("attention.q_proj" if new else "attention.attention.query"): (wq, bq),
+                       ("attention.k_proj" if new else "attention.attention.key"): (wk, bk),
+                       ("attention.v_proj" if new else "attention.attention.value"): (wv, bv),
+                       ("attention.o_proj" if new else "attention.output.dense"): (sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"]),
+                       "layernorm_before": (sd[p + "norm1.weight"], sd[p + "norm1.bias"]), "layernorm_after": (sd[p + "norm2.weight"], sd[p + "norm2.bias"]),
+                       ("mlp.fc1" if new else "intermediate.dense"): (sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]),
+                       ("mlp.fc2" if new else "output.dense"): (sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])}
+            params = dict(lyr.named_parameters())
+            assert set(params) == {k + s for k in mapping for s in (".weight", ".bias")}, sorted(params)
+            for k, (w, b) in mapping.items():
+                params[k + ".weight"].copy_(w); params[k + ".bias"].copy_(b)
+        x = torch.randn(2, 37, D, generator=torch.Generator().manual_seed(0))
+        y_hf = x
+        for lyr in layers:
+            o = lyr(y_hf)
+            y_hf = o[0] if isinstance(o, (tuple, list)) else o
+        y = x
+        for i in range(L):
+            y = midas_vit.timm_block(y, sd, f"backbone.net.vit.blocks.{i}.", heads)
+    assert float((y - y_hf).abs().max() / y_hf.abs().max()) < 2e-5
+    grid = 10
+    img = torch.randn(1, 3, grid * patch, grid * patch, generator=torch.Generator().manual_seed(1))
+    dense = midas_vit.midas_backbone_forward(sd, img, heads, L)
+    assert dense.shape == (1, D, grid, grid)
+    # by hand: tokens = [cls | patches] + resized table, then the blocks
+    V = "backbone.net.vit."
+    t = torch.nn.functional.conv2d(img, sd[V + "patch_embed.proj.weight"], sd[V + "patch_embed.proj.bias"], stride=patch).flatten(2).transpose(1, 2)
+    t = torch.cat([sd[V + "cls_token"], t], 1) + clip_vit.resize_pos_embed(sd[V + "pos_embed"][0], (grid, grid))[None]
+    for i in range(L):
+        t = midas_vit.timm_block(t, sd, V + f"blocks.{i}.", heads)
+    assert torch.equal(dense, t[:, 1:].reshape(1, grid, grid, D).permute(0, 3, 1, 2))
