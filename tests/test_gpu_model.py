@@ -213,6 +213,29 @@ def test_clip_tower_tiny_oracle2d_and_rpn_paths(device):
     _compare(out2, ref2)
 
 
+def test_backbone_level_c_abi(device):
+    """ovm_backbone_num_levels / ovm_backbone_level hand out the pyramid the handle holds (how a non-Python host reads p5 of the
+    4-level towers): sides, strides and contents equal the exported copies; bad arguments are refused."""
+    import ctypes as C
+    for cfg, n in ((build_cfg("vittest14", 224, "f16x3", max_batch=1), 3), (build_clip_cfg("ViT-test-16", 256, "f16x3", max_batch=1), 4)):
+        model, sd = _build(cfg, seed=5)
+        inputs = synth_inputs(1, hw=((160, 224),), n_boxes=4, seed=31)
+        model.backbone.export_features = True
+        feats = model.backbone(model.preprocess_image(inputs))
+        L, h = model.engine._lib, model.engine._h
+        assert L.ovm_backbone_num_levels(h) == n == len(feats)
+        for i, (name, side, stride) in enumerate(model.engine.levels):
+            ptr, s_, st = C.c_void_p(), C.c_int32(), C.c_float()
+            assert L.ovm_backbone_level(h, i, C.byref(ptr), C.byref(s_), C.byref(st)) == 0
+            assert s_.value == side == feats[name].shape[-1] and abs(st.value - stride) < 1e-6
+            got = torch.empty(side * side * model.engine.C, dtype=torch.float32, device=device)
+            torch.cuda.synchronize()
+            C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(got.data_ptr()), ptr, C.c_size_t(got.numel() * 4), 3)   # device to device
+            assert torch.equal(got.view(side, side, -1), feats[name][0].permute(1, 2, 0))
+        assert L.ovm_backbone_level(h, n, None, None, None) != 0 and L.ovm_backbone_level(h, -1, None, None, None) != 0
+        del model
+
+
 def test_clip_tower_refuses_prompt_depth(device):
     """detectron2's SimpleFeaturePyramid.forward takes no depth; the fork would raise a TypeError at rcnn3d.py:97."""
     cfg = build_clip_cfg("ViT-test-16", 256, "f16x3", max_batch=1)
