@@ -83,11 +83,20 @@ typedef struct OvmConfig {
    *                         LayerScale, erf-GELU, LN eps 1e-6, norm_pre = identity, no final norm), position table of the 24 x 24
    *                         grid resized with the CLIP tower's antialiased bicubic (:64-66); checkpoint keys backbone.net.vit.*
    *                         in timm's naming (cls_token, pos_embed, patch_embed.proj, blocks.N.{norm1,attn.qkv,attn.proj,norm2,
-   *                         mlp.fc1,mlp.fc2}); same 4-level pyramid and prompt_depth rule as CLIP */
+   *                         mlp.fc1,mlp.fc2}); same 4-level pyramid and prompt_depth rule as CLIP
+   *   OVM_TOWER_SAM    (4)  build_sam_backbone, reference cubercnn/modeling/backbone/sam.py:19-112: segment_anything's ImageEncoderViT
+   *                         blocks (no class token; patch 16 with bias; absolute position table [grid][grid][D], bicubic-resized when
+   *                         the canvas grid differs, :73-86; blocks with 14 x 14 windowed attention over the zero-padded grid except
+   *                         the global ones; decomposed relative-position bias from the query content; erf-GELU, LN eps 1e-6), dense
+   *                         output of the last block, the neck unused; keys backbone.net.vit.{pos_embed, patch_embed.proj,
+   *                         blocks.N.{norm1, attn.qkv, attn.proj, attn.rel_pos_h, attn.rel_pos_w, norm2, mlp.lin1, mlp.lin2}};
+   *                         pos_grid = the checkpoint's grid (64); sam_window / sam_global_mask below */
   int32_t tower;
+  int32_t sam_window;        /* OVM_TOWER_SAM: window side of the windowed blocks (14) */
+  uint32_t sam_global_mask;  /* OVM_TOWER_SAM: bit i set = block i attends globally (vit_b: blocks 2, 5, 8, 11) */
 } OvmConfig;
 
-enum { OVM_TOWER_DINOV2 = 0, OVM_TOWER_CLIP = 1, OVM_TOWER_MAE = 2, OVM_TOWER_MIDAS = 3 };
+enum { OVM_TOWER_DINOV2 = 0, OVM_TOWER_CLIP = 1, OVM_TOWER_MAE = 2, OVM_TOWER_MIDAS = 3, OVM_TOWER_SAM = 4 };
 
 /* One host-resident fp32 tensor of a checkpoint, named with the reference state_dict key
  * (module tree printed at reference nohup.out:563-684; loaded at reference demo/demo.py:148). */

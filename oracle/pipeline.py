@@ -13,12 +13,14 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
-from . import clip_vit, heads, mae_vit, midas_vit, rpn, sfp, vit
+from . import clip_vit, heads, mae_vit, midas_vit, rpn, sam_vit, sfp, vit
 
 
 @dataclass
 class OracleParams:
     model_name: str = "vitl14"
+    sam_window: int = 14                                            # tower 'sam': window side and the global-attention blocks
+    sam_global: Sequence[int] = (2, 5, 8, 11)
     tower: str = "dinov2"                                           # 'dinov2' | 'clip' | 'mae' (build_*_backbone); for 'mae' depth = num_layers
     embed_dim: int = 1024
     depth: int = 24
@@ -67,6 +69,9 @@ def backbone(sd, images: torch.Tensor, P: OracleParams, prompt_depth=None) -> Di
         # detectron2's SimpleFeaturePyramid.forward(x) has no depth argument: the fork's rcnn3d.py:97 call with one raises
         assert prompt_depth is None, "the CLIP backbone takes no prompt_depth (SURVEY.md 0.4)"
         return sfp.sfp4_forward(sd, clip_vit.clip_backbone_forward(sd, images, P.heads, P.depth))
+    if P.tower == "sam":
+        assert prompt_depth is None, "the SAM backbone takes no prompt_depth (SURVEY.md 0.4)"
+        return sfp.sfp4_forward(sd, sam_vit.sam_backbone_forward(sd, images, P.heads, P.depth, P.sam_window, P.sam_global))
     if P.tower == "midas":
         assert prompt_depth is None, "the MiDaS backbone takes no prompt_depth (SURVEY.md 0.4)"
         return sfp.sfp4_forward(sd, midas_vit.midas_backbone_forward(sd, images, P.heads, P.depth))

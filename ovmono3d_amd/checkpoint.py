@@ -41,7 +41,7 @@ class DetectionCheckpointer:
             seed = int(q.split("=")[1]) if q.startswith("seed=") else 0
             cfg = self.model.cfg
             default = {"build_clip_backbone": cfg.MODEL.CLIP.ARCH, "build_mae_backbone": cfg.MODEL.MAE.CHECKPOINT,
-                       "build_midas_backbone": cfg.MODEL.MIDAS.ARCH}.get(
+                       "build_midas_backbone": cfg.MODEL.MIDAS.ARCH, "build_sam_backbone": cfg.MODEL.SAM.ARCH}.get(
                 cfg.MODEL.BACKBONE.NAME, cfg.MODEL.DINO.MODEL_NAME)
             sd = synth_state_dict(name or default,
                                   num_classes=self.model.cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=seed)

@@ -242,6 +242,9 @@ def get_cfg_defaults(cfg: CfgNode) -> CfgNode:
     # MiDaS DPT_Large's ViT-L/16 (reference config.py:107-110, backbone/midas_final.py; 'build_midas_backbone'). The reference hard-codes
     # the hub model; ARCH is a native-build key that selects the architecture table entry (tests use a small one)
     cfg.MODEL.MIDAS = CfgNode(dict(ARCH="DPT_Large", OUTPUT="dense", LAYER=-1, RETURN_MULTILAYER=False))
+    # SAM ViT-B image encoder (reference config.py:112-115, backbone/sam.py; 'build_sam_backbone'); the reference hard-codes
+    # sam_model_registry['vit_b']; ARCH is a native-build key as for MiDaS
+    cfg.MODEL.SAM = CfgNode(dict(ARCH="vit_b", OUTPUT="dense", LAYER=-1, RETURN_MULTILAYER=False))
 
     H = CfgNode()
     H.NAME = "CubeHead"

@@ -12,6 +12,7 @@
 #include "../../include/ovm3d.h"
 #include "kernels.hpp"
 #include "det2d.hpp"
+#include "gdino.hpp"
 
 using namespace ovm;
 
@@ -28,6 +29,9 @@ struct PackedLinear { Split w; float* bias = nullptr; int N = 0, K = 0; };
 struct Layer {
   float *ln1g, *ln1b, *ln2g, *ln2b, *ls1, *ls2;
   PackedLinear qkv, proj, fc1, fc2;
+  // SAM tower: window side of the block (0 = global attention) and its relative-position tables [2 s - 1][64] (s = window side,
+  // or the canvas grid for a global block: resized at create when the checkpoint's table has another length)
+  int ws = 0; float *relh = nullptr, *relw = nullptr;
 };
 
 struct SfpStage {              // 1x1 conv + LN, 3x3 conv + LN
@@ -58,6 +62,10 @@ struct OvmHandle {
   // weights
   PackedLinear pe; float *cls = nullptr, *pos = nullptr;
   float *lnpre_g = nullptr, *lnpre_b = nullptr;                 // open_clip ln_pre
+  // SAM tower (windowed blocks run on window-partitioned rows like the Swin backbone of the detector)
+  bool sam = false; int sam_ws = 0, sam_nw = 0, sam_rows = 0;   // window side, windows per image, rows per image of the partitioned layout
+  int* sam_map = nullptr;                                       // [max_batch][sam_rows]: token row of X, -1 = padding
+  Split XW, CTX; float *QKVF = nullptr, *RELH = nullptr, *RELW = nullptr; int ldrel = 0;
   std::vector<Layer> layers;
   PackedLinear dfuse; bool has_dfuse = false;
   PackedLinear convt;                                           // ConvT D -> D/2 (first layer of the scale-2 and scale-4 stages... per stage)
@@ -497,6 +505,60 @@ int ovm_host_resize_pos_embed_aa(const float* pos, int32_t M, int32_t D, int32_t
   return OVM_OK;
 }
 
+}  // extern "C" (host helpers with internal linkage follow)
+
+// F.interpolate(src[1,D,M,M], size=(G,G), mode="bicubic", align_corners=False) on a channels-last table [M*M][D] -> [G*G][D]
+// (A = -0.75, border indices clamped, x pass then y as upsample_bicubic2d evaluates it); scale = the source step per output pixel
+static int host_bicubic_grid(const float* src, int M, int D, int G, float scale, float* dst) {
+  if (M <= 0 || D <= 0 || G <= 0) return OVM_ERR_INVALID;
+  if (G == M) { memcpy(dst, src, (size_t)M * M * D * 4); return OVM_OK; }
+  auto coef = [](float t, float* w) {
+    const float A = -0.75f;
+    auto c1 = [&](float x) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; };
+    auto c2 = [&](float x) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; };
+    w[0] = c2(t + 1.f); w[1] = c1(t); w[2] = c1(1.f - t); w[3] = c2(2.f - t);
+  };
+  for (int oy = 0; oy < G; ++oy) {
+    const float ry = scale * ((float)oy + 0.5f) - 0.5f;
+    const int iy = (int)floorf(ry);
+    float wy[4]; coef(ry - (float)iy, wy);
+    for (int ox = 0; ox < G; ++ox) {
+      const float rx = scale * ((float)ox + 0.5f) - 0.5f;
+      const int ix = (int)floorf(rx);
+      float wx[4]; coef(rx - (float)ix, wx);
+      float* o = dst + ((size_t)oy * G + ox) * D;
+      for (int d = 0; d < D; ++d) o[d] = 0.f;
+      for (int a = 0; a < 4; ++a) {
+        int yy = iy - 1 + a; yy = yy < 0 ? 0 : (yy > M - 1 ? M - 1 : yy);
+        for (int d = 0; d < D; ++d) {
+          float acc = 0.f;
+          for (int b = 0; b < 4; ++b) {
+            int xx = ix - 1 + b; xx = xx < 0 ? 0 : (xx > M - 1 ? M - 1 : xx);
+            acc += src[((size_t)yy * M + xx) * D + d] * wx[b];
+          }
+          o[d] += acc * wy[a];
+        }
+      }
+    }
+  }
+  return OVM_OK;
+}
+
+// F.interpolate(src[1,C,L], size=Lo, mode="linear", align_corners=False) on rows [L][C] -> [Lo][C]
+static void host_linear_rows(const float* src, int L, int C, int Lo, float* dst) {
+  if (L == Lo) { memcpy(dst, src, (size_t)L * C * 4); return; }
+  const float scale = (float)L / (float)Lo;
+  for (int o = 0; o < Lo; ++o) {
+    float f = scale * ((float)o + 0.5f) - 0.5f; if (f < 0.f) f = 0.f;
+    int i0 = (int)f; if (i0 > L - 1) i0 = L - 1;
+    const int i1 = i0 + (i0 < L - 1 ? 1 : 0);
+    const float l1 = f - (float)i0, l0 = 1.f - l1;
+    for (int c = 0; c < C; ++c) dst[(size_t)o * C + c] = l0 * src[(size_t)i0 * C + c] + l1 * src[(size_t)i1 * C + c];
+  }
+}
+
+extern "C" {
+
 int ovm_host_sincos_pos_embed(int32_t D, int32_t G, float* out) {
   if (D <= 0 || D % 4 != 0 || G <= 0) return OVM_ERR_INVALID;
   const int Q = D / 4;                                       // frequencies per (coordinate, sin / cos)
@@ -522,8 +584,10 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
   *out = h;
   h->cfg = *cfg; h->device = device;
   const OvmConfig& c = h->cfg;
-  const bool clip = c.tower == OVM_TOWER_CLIP, mae = c.tower == OVM_TOWER_MAE, midas = c.tower == OVM_TOWER_MIDAS;
-  const bool p16 = clip || mae || midas;                  // patch-16 towers behind the 4-level pyramid
+  const bool clip = c.tower == OVM_TOWER_CLIP, mae = c.tower == OVM_TOWER_MAE, midas = c.tower == OVM_TOWER_MIDAS, sam = c.tower == OVM_TOWER_SAM;
+  const bool p16 = clip || mae || midas || sam;           // patch-16 towers behind the 4-level pyramid
+  h->sam = sam;
+  if (sam && (c.sam_window < 1 || c.depth > 32 || c.pos_grid < 1)) { h->err = "invalid config (sam_window, depth <= 32, pos_grid)"; return OVM_ERR_INVALID; }
   if (c.tower != OVM_TOWER_DINOV2 && !p16) { h->err = "invalid config (tower)"; return OVM_ERR_INVALID; }
   h->patch = p16 ? 16 : 14; h->nlev = p16 ? 4 : 3;
   h->ln_eps = clip ? 1e-5f : (mae ? 1e-12f : 1e-6f); h->mlp_act = clip ? 3 : 0;
@@ -537,7 +601,7 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
   HCHECK(h, hipSetDevice(device));
   h->npass = c.precision;
   h->D = c.embed_dim; h->C = c.fpn_channels;
-  h->G = c.canvas / h->patch; h->G2 = h->G * h->G; h->T = h->G2 + 1; h->Tpad = (h->T + 63) / 64 * 64;
+  h->G = c.canvas / h->patch; h->G2 = h->G * h->G; h->T = h->G2 + (sam ? 0 : 1); h->Tpad = (h->T + 63) / 64 * 64;
   const int D = h->D, C = h->C, G = h->G, G2 = h->G2, T = h->T, L = c.depth, B = c.max_batch, R = c.max_rois;
   WeightMap wm;
   for (int i = 0; i < n_weights; ++i) wm.m[weights[i].name] = &weights[i];
@@ -562,6 +626,10 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
       r = ovm_host_resize_pos_embed_aa(pos, c.pos_grid, D, G, pi.data()); if (r) return r;
       r = upload_f32(h, wm, V + "ln_pre.weight", D, &h->lnpre_g); if (r) return r;
       r = upload_f32(h, wm, V + "ln_pre.bias", D, &h->lnpre_b); if (r) return r;
+    } else if (sam) {                                      // segment_anything: no class token, table [grid][grid][D], plain bicubic resize (sam.py:73-86)
+      r = upload_f32(h, wm, V + "patch_embed.proj.bias", D, &h->pe.bias); if (r) return r;
+      r = get_host(h, wm, V + "pos_embed", (int64_t)c.pos_grid * c.pos_grid * D, &pos); if (r) return r;
+      r = host_bicubic_grid(pos, c.pos_grid, D, G, (float)c.pos_grid / (float)G, pi.data()); if (r) return r;
     } else if (mae) {                                      // HF ViTMAE embeddings, position table rebuilt for this grid (mae.py:62-78)
       r = upload_f32(h, wm, V + "embeddings.patch_embeddings.projection.bias", D, &h->pe.bias); if (r) return r;
       r = upload_f32(h, wm, V + "embeddings.cls_token", D, &h->cls); if (r) return r;
@@ -590,6 +658,29 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
       if ((r = pack_linear(h, wm, Pq + "attn.out_proj", D, D, &y.proj))) return r;
       if ((r = pack_linear(h, wm, Pq + "mlp.c_fc", 4 * D, D, &y.fc1))) return r;
       if ((r = pack_linear(h, wm, Pq + "mlp.c_proj", D, 4 * D, &y.fc2))) return r;
+      continue;
+    }
+    if (sam) {                                             // segment_anything Block: norm1, attn (qkv, proj, rel_pos_h / _w), norm2, mlp (lin1, lin2)
+      const std::string Pq = V + "blocks." + std::to_string(l) + ".";
+      if ((r = upload_f32(h, wm, Pq + "norm1.weight", D, &y.ln1g))) return r;
+      if ((r = upload_f32(h, wm, Pq + "norm1.bias", D, &y.ln1b))) return r;
+      if ((r = upload_f32(h, wm, Pq + "norm2.weight", D, &y.ln2g))) return r;
+      if ((r = upload_f32(h, wm, Pq + "norm2.bias", D, &y.ln2b))) return r;
+      y.ls1 = y.ls2 = nullptr;
+      if ((r = pack_linear(h, wm, Pq + "attn.qkv", 3 * D, D, &y.qkv))) return r;
+      if ((r = pack_linear(h, wm, Pq + "attn.proj", D, D, &y.proj))) return r;
+      if ((r = pack_linear(h, wm, Pq + "mlp.lin1", 4 * D, D, &y.fc1))) return r;
+      if ((r = pack_linear(h, wm, Pq + "mlp.lin2", D, 4 * D, &y.fc2))) return r;
+      y.ws = ((c.sam_global_mask >> l) & 1u) ? 0 : c.sam_window;
+      const int side = y.ws ? y.ws : G;                    // the attention grid of this block
+      for (int hw = 0; hw < 2; ++hw) {
+        const std::string key = Pq + (hw ? "attn.rel_pos_w" : "attn.rel_pos_h");
+        const OvmTensor* t = wm.get(key);
+        if (!t || t->ndim != 2 || t->shape[1] != 64) { h->err = "missing or mis-shaped weight: " + key; return OVM_ERR_MISSING_WEIGHT; }
+        std::vector<float> tab((size_t)(2 * side - 1) * 64);
+        host_linear_rows(t->data, (int)t->shape[0], 64, 2 * side - 1, tab.data());     // get_rel_pos: F.interpolate(mode="linear") when lengths differ
+        if ((r = upload_vec(h, tab, hw ? &y.relw : &y.relh))) return r;
+      }
       continue;
     }
     if (mae) {                                             // HF ViTLayer: layernorm_before, attention (q / k / v / output.dense), layernorm_after, MLP
@@ -689,6 +780,28 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
     if ((r = dalloc(h, &h->dtok, MP))) return r;
     if ((r = dalloc(h, &h->FUS, MP * D))) return r;
   }
+  if (sam) {
+    const int ws = c.sam_window, gp = (G + ws - 1) / ws * ws, nw1 = gp / ws;
+    h->sam_ws = ws; h->sam_nw = nw1 * nw1; h->sam_rows = h->sam_nw * ws * ws;
+    std::vector<int> map((size_t)B * h->sam_rows);
+    for (int b = 0; b < B; ++b)
+      for (int wy = 0; wy < nw1; ++wy)
+        for (int wx = 0; wx < nw1; ++wx)
+          for (int iy = 0; iy < ws; ++iy)
+            for (int ix = 0; ix < ws; ++ix) {
+              const int y = wy * ws + iy, x = wx * ws + ix;          // window_partition pads bottom / right (segment_anything)
+              map[(size_t)b * h->sam_rows + ((size_t)(wy * nw1 + wx) * ws + iy) * ws + ix] = (y < G && x < G) ? b * T + y * G + x : -1;
+            }
+    if ((r = dalloc(h, &h->sam_map, map.size()))) return r;
+    HCHECK(h, hipMemcpy(h->sam_map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+    const size_t MW = (size_t)B * (h->sam_rows > T ? h->sam_rows : T);
+    h->ldrel = ((ws > G ? ws : G) + 3) / 4 * 4;
+    if ((r = salloc(h, &h->XW, MW * D))) return r;
+    if ((r = salloc(h, &h->CTX, MW * D))) return r;
+    if ((r = dalloc(h, &h->QKVF, MW * 3 * D))) return r;
+    if ((r = dalloc(h, &h->RELH, MW * c.heads * h->ldrel))) return r;
+    if ((r = dalloc(h, &h->RELW, MW * c.heads * h->ldrel))) return r;
+  }
   const int G2x = 2 * G, G4 = G / 2;
   if ((r = salloc(h, &h->CT, (size_t)B * G2x * G2x * (D / 2)))) return r;
   if (p16) {
@@ -780,7 +893,7 @@ int ovm_backbone_forward(OvmHandle* h, const OvmImage* images, int32_t B, const 
     h->err = "prompt_depth is only defined for the DINOv2 tower (depth_fusion, dino.py:91-105)"; return OVM_ERR_INVALID;
   }
   KCHECK(h, launch_patch_gather(h->d_imgs, B, G, h->patch, h->Kpe, c.pixel_mean, c.pixel_std, h->PA.hi, h->PA.lo, s));
-  KCHECK(h, launch_cls_init(h->X, h->cls, h->pos, B, T, D, s));
+  if (!h->sam) KCHECK(h, launch_cls_init(h->X, h->cls, h->pos, B, T, D, s));       // SAM: no class token (T = G^2)
   {
     GemmParams p = gp_base(h->PA, h->Kpe, h->pe, B * G2);
     p.X = h->X; p.ldx = D; p.pos = h->pos; p.G2 = G2; p.T = T;
@@ -796,6 +909,42 @@ int ovm_backbone_forward(OvmHandle* h, const OvmImage* images, int32_t B, const 
     const Layer& y = h->layers[l];
     const int il = h->npass == 3 ? 1 : 0, am = il ? 2 : 1;    // activations of the blocks: interleaved split images in f16x3 mode
     LnOut o; memset(&o, 0, sizeof(o)); o.hi = h->HN.hi; o.lo = h->HN.lo; o.ld = am * D; o.il = il;
+    if (h->sam) {
+      // segment_anything Block (reference sam.py:100-106 runs vit.blocks as they are): norm1 -> [zero-padded 14 x 14 windows] ->
+      // attention with the decomposed relative-position bias -> [un-partition] -> + shortcut. Same organisation as a Swin block of
+      // the detector: the norm writes window-partitioned rows (padding rows zero AFTER the norm), the projection's epilogue
+      // scatters back through the same map and adds the shortcut. Scores are exact fp32 products on the matrix cores (attn_f32).
+      const int ws = y.ws, rows = ws ? h->sam_rows : T, Mw = B * rows, side = ws ? ws : G, Tq = side * side, nseq = Mw / Tq;
+      {
+        RowOpParams rp; memset(&rp, 0, sizeof(rp));
+        rp.x = h->X; rp.ldx = D; rp.gamma = y.ln1g; rp.beta = y.ln1b; rp.eps = eps; rp.M = Mw; rp.D = D;
+        if (ws) { rp.idx = h->sam_map; rp.nidx = 1; rp.seg = D; rp.zero_masked = 1; }
+        rp.hi = h->XW.hi; rp.lo = h->XW.lo; rp.ldh = D;
+        ProfScope ps(h, OVM_PROF_LN, s); KCHECK(h, launch_rowop(rp, s));
+      }
+      {
+        GemmParams p = gp_base(h->XW, D, y.qkv, Mw);
+        p.C = h->QKVF; p.ldc = 3 * D;
+        KCHECK(h, gemm(h, p, EPI_STORE, A_ROWMAJOR, s, OVM_PROF_QKV));
+      }
+      {
+        ProfScope ps(h, OVM_PROF_ATTN, s);
+        // the bias tables use the UNSCALED query (add_decomposed_rel_pos is given q, the scores use q * scale)
+        KCHECK(h, launch_relpos_tables(h->QKVF, 3 * D, Mw, c.heads, 64, side, side, y.relh, y.relw, h->RELH, h->RELW, h->ldrel, s));
+        AttnF32Params a; memset(&a, 0, sizeof(a));
+        a.q = h->QKVF; a.k = h->QKVF + D; a.v = h->QKVF + 2 * D; a.ldq = a.ldk = a.ldv = 3 * D;
+        a.sq1 = a.sk1 = a.sv1 = (long)Tq * 3 * D; a.sq2 = a.sk2 = a.sv2 = 64;
+        a.ohi = h->CTX.hi; a.olo = h->CTX.lo; a.ldoh = D; a.soh1 = (long)Tq * D; a.soh2 = 64;
+        a.nb1 = nseq; a.nb2 = c.heads; a.Tq = Tq; a.Tk = Tq; a.DH = 64; a.scale = 0.125f;
+        a.rel_h = h->RELH; a.rel_w = h->RELW; a.rel_gw = side; a.ldrel = h->ldrel;
+        KCHECK(h, launch_attn_f32(a, s));
+      }
+      {
+        GemmParams p = gp_base(h->CTX, D, y.proj, Mw);
+        p.X = h->X; p.ldx = D; p.row_map = ws ? h->sam_map : nullptr;
+        KCHECK(h, gemm(h, p, EPI_RESID, A_ROWMAJOR, s, OVM_PROF_PROJ));
+      }
+    } else {
     { ProfScope ps(h, OVM_PROF_LN, s); KCHECK(h, launch_ln_rows(h->X, D, M, D, y.ln1g, y.ln1b, eps, o, s)); }
     {
       GemmParams p = gp_base(h->HN, am * D, y.qkv, M); p.a_il = il;
@@ -814,6 +963,7 @@ int ovm_backbone_forward(OvmHandle* h, const OvmImage* images, int32_t B, const 
       GemmParams p = gp_base(h->AO, am * D, y.proj, M); p.a_il = il;
       p.gamma = y.ls1; p.X = h->X; p.ldx = D;
       KCHECK(h, gemm(h, p, EPI_RESID, A_ROWMAJOR, s, OVM_PROF_PROJ));
+    }
     }
     { ProfScope ps(h, OVM_PROF_LN, s); KCHECK(h, launch_ln_rows(h->X, D, M, D, y.ln2g, y.ln2b, eps, o, s)); }
     {

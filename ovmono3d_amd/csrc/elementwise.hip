@@ -235,7 +235,7 @@ __global__ void tokens_cast_kernel(const float* __restrict__ X, int B, int T, in
   half4 h, l;
   const int n = j * 4;
   if (n < D) {
-    const f32x4 v = *(const f32x4*)(X + ((size_t)b * T + 1 + p) * D + n);
+    const f32x4 v = *(const f32x4*)(X + ((size_t)b * T + (T - G2) + p) * D + n);     // T - G2 leading (class) tokens
 #pragma unroll
     for (int q = 0; q < 4; ++q) { half_t hh, ll; split_f16(v[q], hh, ll); h[q] = hh; l[q] = ll; }
   } else {
@@ -262,7 +262,7 @@ __global__ void tokens_writeback_kernel(float* __restrict__ X, const float* __re
   const int j = (int)(idx % (D / 4));
   const size_t r = idx / (D / 4);
   const int b = (int)(r / G2), p = (int)(r - (size_t)b * G2);
-  ((f32x4*)(X + ((size_t)b * T + 1 + p) * D))[j] = ((const f32x4*)(F + r * D))[j];
+  ((f32x4*)(X + ((size_t)b * T + (T - G2) + p) * D))[j] = ((const f32x4*)(F + r * D))[j];
 }
 int launch_tokens_writeback(float* X, const float* F, int B, int T, int G2, int D, hipStream_t s) {
   const size_t total = (size_t)B * G2 * (D / 4);

@@ -33,8 +33,17 @@ struct AttnF32Params {
   int nb1, nb2, Tq, Tk, DH; float scale;
   const float* bias_h; long sbh; int ldbh;         // [nb2][Tq][ldbh] or null
   const float* bias_b; long sbb; int ldbb;         // [nb1][Tq][ldbb] or null (sbb = 0: shared by all b1)
+  // decomposed relative-position bias of the SAM image encoder (segment_anything add_decomposed_rel_pos): keys lie on a
+  // rel_gh x rel_gw grid (key = kh * rel_gw + kw) and score(q, key) += rel_h[q][kh] + rel_w[q][kw]; both tables depend on the
+  // query's content and are laid out [b1][q][b2][ldrel] (launch_relpos_tables writes them). null: none
+  const float* rel_h; const float* rel_w; int rel_gw; int ldrel;
 };
 int launch_attn_f32(const AttnF32Params& p, hipStream_t s);
+
+// rel_h[(m * H + h)][kh] = q[m][h*DH : (h+1)*DH] . Rh[qh - kh + gh - 1], rel_w likewise over kw with Rw and qw, for the rows m of
+// fp32 q (row stride ldq); a row's position on its gh x gw attention grid is (t / gw, t % gw) with t = m % (gh * gw)
+int launch_relpos_tables(const float* q, int ldq, int M, int H, int DH, int gh, int gw, const float* Rh, const float* Rw, float* rel_h,
+                         float* rel_w, int ldrel, hipStream_t s);
 
 // ---- bi-directional image <-> text attention of the fusion layer (4 heads x 256, T text tokens, S image tokens) ---------------
 struct BiAttnParams {

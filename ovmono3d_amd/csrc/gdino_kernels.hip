@@ -157,6 +157,9 @@ __global__ __launch_bounds__(576) void attn_f32_kernel(const AttnF32Params p) {
   }
   const float* bh = p.bias_h ? p.bias_h + (size_t)b2 * p.sbh + (size_t)qi * p.ldbh : nullptr;
   const float* bb = p.bias_b ? p.bias_b + (size_t)b1 * p.sbb + (size_t)qi * p.ldbb : nullptr;
+  const size_t relrow = (((size_t)b1 * p.Tq + qi) * p.nb2 + b2) * (size_t)p.ldrel;
+  const float* rh = p.rel_h ? p.rel_h + relrow : nullptr;
+  const float* rw = p.rel_h ? p.rel_w + relrow : nullptr;
   f32x4 o[ND];
 #pragma unroll
   for (int d = 0; d < ND; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -196,6 +199,7 @@ __global__ __launch_bounds__(576) void attn_f32_kernel(const AttnF32Params p) {
           if (key < p.Tk) {
             if (bh) x += bh[key] * kLog2e;
             if (bb) x += bb[key] * kLog2e;
+            if (rh) { const int kh = key / p.rel_gw; x += (rh[kh] + rw[key - kh * p.rel_gw]) * kLog2e; }
           } else {
             x = -INFINITY;
           }
@@ -526,6 +530,38 @@ int launch_attn_f32(const AttnF32Params& p, hipStream_t s) {
   else if (p.DH == 64) OVM_ATTN_F32(64)
   else return OVM_ERR_SHAPE;
 #undef OVM_ATTN_F32
+  return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
+
+__global__ void relpos_tables_kernel(const float* __restrict__ q, int ldq, int M, int H, int DH, int gh, int gw, const float* __restrict__ Rh,
+                                     const float* __restrict__ Rw, float* __restrict__ rel_h, float* __restrict__ rel_w, int ldrel) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per = gh + gw;
+  const long total = (long)M * H * per;
+  if (idx >= total) return;
+  const int j = (int)(idx % per);
+  const long mh = idx / per;
+  const int h = (int)(mh % H);
+  const long m = mh / H;
+  const int t = (int)(m % ((long)gh * gw));
+  const int qh = t / gw, qw = t - qh * gw;
+  const float* qr = q + (size_t)m * ldq + (size_t)h * DH;
+  const bool is_h = j < gh;
+  const int kk = is_h ? j : j - gh;
+  const float* r = is_h ? Rh + (size_t)(qh - kk + gh - 1) * DH : Rw + (size_t)(qw - kk + gw - 1) * DH;
+  float acc = 0.f;
+  for (int c = 0; c < DH; c += 4) {
+    const f32x4 a = *(const f32x4*)(qr + c);
+    const f32x4 b = *(const f32x4*)(r + c);
+    acc += a[0] * b[0]; acc += a[1] * b[1]; acc += a[2] * b[2]; acc += a[3] * b[3];
+  }
+  (is_h ? rel_h : rel_w)[(size_t)mh * ldrel + kk] = acc;
+}
+
+int launch_relpos_tables(const float* q, int ldq, int M, int H, int DH, int gh, int gw, const float* Rh, const float* Rw, float* rel_h,
+                         float* rel_w, int ldrel, hipStream_t s) {
+  if (DH % 4 || ldq % 4 || gh > ldrel || gw > ldrel || M <= 0) return M <= 0 ? OVM_OK : OVM_ERR_SHAPE;
+  hipLaunchKernelGGL(relpos_tables_kernel, g1((long)M * H * (gh + gw)), dim3(256), 0, s, q, ldq, M, H, DH, gh, gw, Rh, Rw, rel_h, rel_w, ldrel);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 

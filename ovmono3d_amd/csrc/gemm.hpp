@@ -56,7 +56,7 @@ struct GemmParams {
   int padH, padW;
   // EPI_QKV
   half_t *Qhi, *Qlo, *Khi, *Klo, *Vhi, *Vlo; int T, Tpad, heads; float qscale;
-  // EPI_PATCH: X[(b*T + 1 + p)][n] = acc + bias[n] + pos[(1+p)*N + n],   m = b*G2 + p
+  // EPI_PATCH: X[(b*T + c + p)][n] = acc + bias[n] + pos[(c+p)*N + n],   m = b*G2 + p, c = T - G2 leading (class) tokens (1 or 0)
   const float* pos; int G2;
   // EPI_CONVT: m = (b, i, j) over GxG, n = (a*2 + bb)*Cout + co -> NHWC [B][2G][2G][Cout]
   int G, Cout;
@@ -184,9 +184,9 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, f32
       }
     }
   } else if (EPI == EPI_PATCH) {
-    const int b = m / p.G2, pp = m - b * p.G2;
-    float* x = p.X + ((size_t)b * p.T + 1 + pp) * p.ldx + n;
-    const float* ps = p.pos + (size_t)(1 + pp) * p.N + n;
+    const int b = m / p.G2, pp = m - b * p.G2, c0 = p.T - p.G2;
+    float* x = p.X + ((size_t)b * p.T + c0 + pp) * p.ldx + n;
+    const float* ps = p.pos + (size_t)(c0 + pp) * p.N + n;
     for (int r = 0; r < 4 && n + r < p.N; ++r) x[r] = v[r] + b4[r] + ps[r];
   } else if (EPI == EPI_CONVT) {
     const int q = n / p.Cout, co = n - q * p.Cout;       // q = a*2 + bb; Cout % 4 == 0

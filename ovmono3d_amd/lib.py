@@ -31,11 +31,11 @@ class OvmConfig(C.Structure):
         ("rpn_pre_topk", C.c_int32), ("rpn_post_topk", C.c_int32), ("rpn_nms_thresh", C.c_float),
         ("score_thresh", C.c_float), ("nms_thresh", C.c_float), ("detections_per_image", C.c_int32),
         ("precision", C.c_int32), ("max_batch", C.c_int32), ("max_rois", C.c_int32),
-        ("tower", C.c_int32),
+        ("tower", C.c_int32), ("sam_window", C.c_int32), ("sam_global_mask", C.c_uint32),
     ]
 
 
-OVM_TOWER_DINOV2, OVM_TOWER_CLIP, OVM_TOWER_MAE, OVM_TOWER_MIDAS = 0, 1, 2, 3
+OVM_TOWER_DINOV2, OVM_TOWER_CLIP, OVM_TOWER_MAE, OVM_TOWER_MIDAS, OVM_TOWER_SAM = 0, 1, 2, 3, 4
 
 
 class OvmTensor(C.Structure):

@@ -12,8 +12,8 @@ import numpy as np
 import torch
 
 from . import lib as _lib
-from .lib import OVM_REC_FLOATS, OVM_TOWER_CLIP, OVM_TOWER_DINOV2, OVM_TOWER_MAE, OVM_TOWER_MIDAS, OvmConfig, OvmImage, check
-from .util.synth_weights import CLIP_ARCH, MAE_ARCH, MIDAS_ARCH, VIT_ARCH
+from .lib import OVM_REC_FLOATS, OVM_TOWER_CLIP, OVM_TOWER_DINOV2, OVM_TOWER_MAE, OVM_TOWER_MIDAS, OVM_TOWER_SAM, OvmConfig, OvmImage, check
+from .util.synth_weights import CLIP_ARCH, MAE_ARCH, MIDAS_ARCH, SAM_ARCH, VIT_ARCH
 
 
 def config_to_native(cfg) -> OvmConfig:
@@ -59,9 +59,18 @@ def config_to_native(cfg) -> OvmConfig:
             raise ValueError("native path supports MODEL.MIDAS.OUTPUT 'dense', LAYER -1, single layer")
         D, L, heads, patch, pos_grid = MIDAS_ARCH[name]
         n_levels = 4
+    elif backbone == "build_sam_backbone":
+        tower = OVM_TOWER_SAM
+        name = cfg.MODEL.SAM.ARCH
+        if name not in SAM_ARCH:
+            raise ValueError(f"unsupported MODEL.SAM.ARCH {name!r} (known: {sorted(SAM_ARCH)})")
+        if cfg.MODEL.SAM.OUTPUT != "dense" or cfg.MODEL.SAM.RETURN_MULTILAYER or cfg.MODEL.SAM.LAYER != -1:
+            raise ValueError("native path supports MODEL.SAM.OUTPUT 'dense', LAYER -1, single layer")
+        D, L, heads, patch, pos_grid, sam_window, sam_global = SAM_ARCH[name]
+        n_levels = 4
     else:
         raise ValueError(f"MODEL.BACKBONE.NAME {backbone!r} is not on the native path (build_dino_backbone, build_clip_backbone, "
-                         "build_mae_backbone, build_midas_backbone)")
+                         "build_mae_backbone, build_midas_backbone, build_sam_backbone)")
     H = cfg.MODEL.ROI_CUBE_HEAD
     unsupported = []
     if H.Z_TYPE != "direct": unsupported.append("Z_TYPE")
@@ -81,6 +90,9 @@ def config_to_native(cfg) -> OvmConfig:
         raise ValueError(f"MODEL.FPN.SQUARE_PAD must be a positive multiple of {patch}")
     c = OvmConfig()
     c.tower = tower
+    if tower == OVM_TOWER_SAM:
+        c.sam_window = sam_window
+        c.sam_global_mask = sum(1 << i for i in sam_global)
     c.embed_dim, c.depth, c.heads = D, L, heads
     c.pos_grid = pos_grid
     c.canvas = S

@@ -53,6 +53,14 @@ MIDAS_ARCH = {
 }
 
 
+SAM_ARCH = {
+    # name: (width, layers, heads, patch, checkpoint grid, window, global-attention blocks)   -- reference backbone/sam.py:39-40
+    # (segment_anything sam_model_registry['vit_b']: image 1024 -> 64 x 64 grid, window 14, global blocks 2 5 8 11)
+    "vit_b": (768, 12, 12, 16, 64, 14, (2, 5, 8, 11)),
+    "vit_test": (256, 4, 4, 16, 8, 6, (1, 3)),      # tiny (not a published model)
+}
+
+
 def _lin(g, out_f, in_f, std=None, bias_std=0.02):
     std = (1.0 / math.sqrt(in_f)) if std is None else std
     w = torch.randn(out_f, in_f, generator=g) * std
@@ -70,6 +78,8 @@ def synth_state_dict(model_name: str = "vitl14", num_classes: int = 50, fpn_chan
         return synth_mae_state_dict(model_name, num_classes, fpn_channels, fc_dim, pooler_res, seed, num_anchors)
     if model_name in MIDAS_ARCH:
         return synth_midas_state_dict(model_name, num_classes, fpn_channels, fc_dim, pooler_res, seed, num_anchors)
+    if model_name in SAM_ARCH:
+        return synth_sam_state_dict(model_name, num_classes, fpn_channels, fc_dim, pooler_res, seed, num_anchors)
     D, L, _ = VIT_ARCH[model_name]
     g = torch.Generator().manual_seed(seed)
     sd: Dict[str, torch.Tensor] = {}
@@ -295,6 +305,37 @@ def synth_midas_state_dict(arch: str = "DPT_Large", num_classes: int = 50, fpn_c
         sd[B + "mlp.fc2.weight"], sd[B + "mlp.fc2.bias"] = _lin(g, D, 4 * D, std=0.5 / math.sqrt(4 * D))
     sd[V + "norm.weight"] = torch.ones(D)
     sd[V + "norm.bias"] = torch.zeros(D)
+    _synth_neck4(sd, g, D, fpn_channels)
+    _synth_heads(sd, g, fpn_channels, num_classes, fc_dim, pooler_res, num_anchors)
+    return sd
+
+
+def synth_sam_state_dict(arch: str = "vit_b", num_classes: int = 50, fpn_channels: int = 256, fc_dim: int = 1024, pooler_res: int = 7,
+                         seed: int = 0, num_anchors: int = 3) -> Dict[str, torch.Tensor]:
+    """Random-init checkpoint with the key tree of the reference's SAM variant: ``backbone.net.vit.*`` is segment_anything's
+    ``ImageEncoderViT`` (``sam.image_encoder``, reference backbone/sam.py:39-40,49; its neck exists but the dense tap never reaches it), then
+    the 4-level pyramid and the heads. Relative-position tables are given real values (they are zero-initialised upstream and learned)."""
+    D, L, H, P, M, ws, glob = SAM_ARCH[arch]
+    dh = D // H
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    V = "backbone.net.vit."
+    sd[V + "pos_embed"] = torch.randn(1, M, M, D, generator=g) * 0.02
+    sd[V + "patch_embed.proj.weight"] = torch.randn(D, 3, P, P, generator=g) * (1.0 / math.sqrt(3.0 * P * P))
+    sd[V + "patch_embed.proj.bias"] = torch.randn(D, generator=g) * 0.02
+    for i in range(L):
+        B = V + f"blocks.{i}."
+        for n in ("norm1", "norm2"):
+            sd[B + n + ".weight"] = 0.5 + torch.rand(D, generator=g)
+            sd[B + n + ".bias"] = torch.randn(D, generator=g) * 0.05
+        sd[B + "attn.qkv.weight"], sd[B + "attn.qkv.bias"] = _lin(g, 3 * D, D, std=2.0 / math.sqrt(D))
+        sd[B + "attn.proj.weight"], sd[B + "attn.proj.bias"] = _lin(g, D, D, std=0.5 / math.sqrt(D))
+        side = M if i in glob else ws
+        sd[B + "attn.rel_pos_h"] = torch.randn(2 * side - 1, dh, generator=g) * 0.05
+        sd[B + "attn.rel_pos_w"] = torch.randn(2 * side - 1, dh, generator=g) * 0.05
+        sd[B + "mlp.lin1.weight"], sd[B + "mlp.lin1.bias"] = _lin(g, 4 * D, D)
+        sd[B + "mlp.lin2.weight"], sd[B + "mlp.lin2.bias"] = _lin(g, D, 4 * D, std=0.5 / math.sqrt(4 * D))
+    sd[V + "neck.0.weight"] = torch.randn(256, D, 1, 1, generator=g) * 0.02
     _synth_neck4(sd, g, D, fpn_channels)
     _synth_heads(sd, g, fpn_channels, num_classes, fc_dim, pooler_res, num_anchors)
     return sd

@@ -12,7 +12,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from ovmono3d_amd.defaults import make_cfg  # noqa: E402
-from ovmono3d_amd.util.synth_weights import CLIP_ARCH, MAE_ARCH, MIDAS_ARCH, VIT_ARCH, synth_state_dict  # noqa: E402
+from ovmono3d_amd.util.synth_weights import CLIP_ARCH, MAE_ARCH, MIDAS_ARCH, SAM_ARCH, VIT_ARCH, synth_state_dict  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
@@ -46,10 +46,22 @@ def build_midas_cfg(arch="DPT_test", canvas=256, precision="f16x3", max_batch=2,
     return make_cfg("OVMono3D_midas_SFP.yaml", opts)
 
 
+def build_sam_cfg(arch="vit_test", canvas=256, precision="f16x3", max_batch=2, max_rois=1000, roi_heads="ROIHeads3D", extra=()):
+    opts = ["MODEL.SAM.ARCH", arch, "MODEL.FPN.SQUARE_PAD", canvas, "MODEL.AMD.GEMM_PRECISION", precision,
+            "MODEL.AMD.MAX_BATCH", max_batch, "MODEL.AMD.MAX_ROIS", max_rois, "MODEL.ROI_HEADS.NAME", roi_heads]
+    opts += list(extra)
+    return make_cfg("OVMono3D_sam_SFP.yaml", opts)
+
+
 def oracle_params(cfg):
     from oracle.pipeline import OracleParams
-    if cfg.MODEL.BACKBONE.NAME in ("build_clip_backbone", "build_mae_backbone", "build_midas_backbone"):
-        if cfg.MODEL.BACKBONE.NAME == "build_clip_backbone":
+    if cfg.MODEL.BACKBONE.NAME in ("build_clip_backbone", "build_mae_backbone", "build_midas_backbone", "build_sam_backbone"):
+        extra = {}
+        if cfg.MODEL.BACKBONE.NAME == "build_sam_backbone":
+            name, tower = cfg.MODEL.SAM.ARCH, "sam"
+            D, L, h, patch, _, ws, glob = SAM_ARCH[name]
+            extra = dict(sam_window=ws, sam_global=tuple(glob))
+        elif cfg.MODEL.BACKBONE.NAME == "build_clip_backbone":
             name, tower = cfg.MODEL.CLIP.ARCH, "clip"
             D, L, h, patch, _ = CLIP_ARCH[name]
         elif cfg.MODEL.BACKBONE.NAME == "build_midas_backbone":
@@ -67,7 +79,7 @@ def oracle_params(cfg):
                             rpn_pre_topk=cfg.MODEL.RPN.PRE_NMS_TOPK_TEST, rpn_post_topk=cfg.MODEL.RPN.POST_NMS_TOPK_TEST,
                             rpn_nms=cfg.MODEL.RPN.NMS_THRESH, score_thresh=cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST,
                             nms_thresh=cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST, topk=cfg.TEST.DETECTIONS_PER_IMAGE,
-                            virtual_focal=cfg.MODEL.ROI_CUBE_HEAD.VIRTUAL_FOCAL, pooler_min_level=2, pooler_max_level=5)
+                            virtual_focal=cfg.MODEL.ROI_CUBE_HEAD.VIRTUAL_FOCAL, pooler_min_level=2, pooler_max_level=5, **extra)
     D, L, h = VIT_ARCH[cfg.MODEL.DINO.MODEL_NAME]
     return OracleParams(model_name=cfg.MODEL.DINO.MODEL_NAME, embed_dim=D, depth=L, heads=h,
                         square_pad=cfg.MODEL.FPN.SQUARE_PAD, pixel_mean=tuple(cfg.MODEL.PIXEL_MEAN),

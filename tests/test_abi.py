@@ -28,7 +28,7 @@ def test_struct_layouts_match_header():
     assert lib.OVM_REC_FLOATS * 4 == 192
     assert C.sizeof(lib.OvmImage) == 8 + 4 + 4 + 8 * 3 + 4 + 4 + 36 + 4          # trailing pad to 8
     assert C.sizeof(lib.OvmTensor) == 8 + 8 + 8 + 32
-    assert C.sizeof(lib.OvmConfig) == 4 * 7 + 12 + 12 + 4 * 5 + 4 + 16 + 12 + 4 * 2 + 4 + 4 + 4 + 4 + 4 * 3 + 4
+    assert C.sizeof(lib.OvmConfig) == 4 * 7 + 12 + 12 + 4 * 5 + 4 + 16 + 12 + 4 * 2 + 4 + 4 + 4 + 4 + 4 * 3 + 4 * 3
     # and the library agrees with every mirror (lib.load() also refuses a mismatch)
     L = lib.load()
     for name, mirror in (("OvmConfig", lib.OvmConfig), ("OvmTensor", lib.OvmTensor), ("OvmImage", lib.OvmImage),

@@ -8,7 +8,7 @@ oracle is the fp32 restatement in oracle/."""
 import pytest
 import torch
 
-from common import assert_close, build_cfg, build_clip_cfg, build_mae_cfg, build_midas_cfg, oracle_params, synth_inputs
+from common import assert_close, build_cfg, build_clip_cfg, build_mae_cfg, build_midas_cfg, build_sam_cfg, oracle_params, synth_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -20,7 +20,7 @@ def _build(cfg, seed=1):
     from ovmono3d_amd.modeling import build_model
     from ovmono3d_amd.util.synth_weights import synth_state_dict
     name = {"build_clip_backbone": cfg.MODEL.CLIP.ARCH, "build_mae_backbone": cfg.MODEL.MAE.CHECKPOINT,
-            "build_midas_backbone": cfg.MODEL.MIDAS.ARCH}.get(cfg.MODEL.BACKBONE.NAME,
+            "build_midas_backbone": cfg.MODEL.MIDAS.ARCH, "build_sam_backbone": cfg.MODEL.SAM.ARCH}.get(cfg.MODEL.BACKBONE.NAME,
                                                                                                            cfg.MODEL.DINO.MODEL_NAME)
     sd = synth_state_dict(name, num_classes=cfg.MODEL.ROI_HEADS.NUM_CLASSES, seed=seed)
     model = build_model(cfg)
@@ -344,3 +344,47 @@ def test_midas_tower_tiny_and_dpt_large_canvas1024(device):
         e = assert_close(feats[k], aux["features"][k], 1e-3, k)
         print(f"MiDaS ViT-L/16 @1024 {k}: scale-relative error {e:.2e}")
     _compare(out, ref)
+
+
+# ------------------------------------------------------------------------------------------ SAM tower ("next" row 3 analogue)
+def test_sam_tower_tiny(device):
+    """build_sam_backbone at test size: no class token, position table bicubic-resized 8 -> 16, windowed blocks on a zero-padded grid
+    (16 -> 18 = 3 x 3 windows of 6), global blocks with linearly resized relative-position tables (15 -> 31 entries), the decomposed
+    bias from the unscaled query - against the CPU oracle (reference backbone/sam.py:73-112), batch 2, two image shapes."""
+    from oracle.pipeline import inference
+    cfg = build_sam_cfg("vit_test", 256, "f16x3", max_batch=2)
+    model, sd = _build(cfg, seed=9)
+    inputs = synth_inputs(2, hw=((160, 224), (256, 192)), n_boxes=12, seed=61)
+    out = model(inputs)
+    ref, aux = inference(sd, inputs, oracle_params(cfg), return_aux=True)
+    model.backbone.export_features = True
+    feats = model.backbone(model.preprocess_image(inputs))
+    for k in ("p2", "p3", "p4", "p5"):
+        assert_close(feats[k], aux["features"][k], 2e-4, k)
+    model.backbone.export_features = False
+    _compare(out, ref)
+
+
+def test_sam_vitb_canvas1024(device):
+    """segment_anything vit_b's architecture at its own size: 64 x 64 grid (no table resize), 14 x 14 windows on the grid padded to 70
+    (25 windows, 196 tokens each), global attention over 4096 tokens in blocks 2 / 5 / 8 / 11, against the CPU oracle."""
+    from oracle.pipeline import inference
+    cfg = build_sam_cfg("vit_b", 1024, "f16x3", max_batch=1, max_rois=64)
+    model, sd = _build(cfg, seed=3)
+    inputs = synth_inputs(1, hw=((608, 800),), orig_scale=1.0, n_boxes=32, seed=16)
+    out = model(inputs)
+    torch.set_num_threads(16)
+    ref, aux = inference(sd, inputs, oracle_params(cfg), return_aux=True)
+    model.backbone.export_features = True
+    feats = model.backbone(model.preprocess_image(inputs))
+    for k in ("p2", "p3", "p4", "p5"):
+        e = assert_close(feats[k], aux["features"][k], 1e-3, k)
+        print(f"SAM ViT-B @1024 {k}: scale-relative error {e:.2e}")
+    _compare(out, ref)
+    torch.cuda.synchronize()
+    import time
+    t0 = time.time()
+    for _ in range(5):
+        model.backbone(model.preprocess_image(inputs))
+    torch.cuda.synchronize()
+    print(f"SAM ViT-B @1024 backbone: {(time.time() - t0) / 5 * 1e3:.2f} ms per image")

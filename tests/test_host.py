@@ -46,8 +46,11 @@ def test_config_to_native_validation():
     from common import build_midas_cfg
     d = config_to_native(build_midas_cfg("DPT_Large", 1024))
     assert (d.tower, d.embed_dim, d.depth, d.heads, d.pos_grid, d.pooler_max_level) == (3, 1024, 24, 16, 24, 5)
+    from common import build_sam_cfg
+    a = config_to_native(build_sam_cfg("vit_b", 1024))
+    assert (a.tower, a.embed_dim, a.depth, a.heads, a.pos_grid, a.sam_window, a.sam_global_mask) == (4, 768, 12, 12, 64, 14, 0b100100100100)
     with pytest.raises(ValueError):
-        config_to_native(build_cfg(extra=["MODEL.BACKBONE.NAME", "build_sam_backbone"]))
+        config_to_native(build_cfg(extra=["MODEL.BACKBONE.NAME", "build_dla_from_vision_fpn_backbone"]))
     with pytest.raises(ValueError):
         config_to_native(build_cfg("vitl14", 900))                    # not a multiple of 14
     with pytest.raises(ValueError):

@@ -375,3 +375,40 @@ def test_midas_tower_block_matches_hf_vit_layer():
     for i in range(L):
         t = midas_vit.timm_block(t, sd, V + f"blocks.{i}.", heads)
     assert torch.equal(dense, t[:, 1:].reshape(1, grid, grid, D).permute(0, 3, 1, 2))
+
+
+def test_sam_blocks_match_hf_sam_vision_layers():
+    """oracle/sam_vit.py's blocks (zero-padded windows, decomposed relative-position bias from the unscaled query, linearly resized
+    tables) against Hugging Face ``SamVisionLayer``s of the same architecture - a windowed and a global block, on a grid (16) that is
+    neither a multiple of the window (6) nor the checkpoint's grid (8), so padding and the table resize both take part."""
+    from transformers import SamVisionConfig
+    from transformers.models.sam.modeling_sam import SamVisionLayer
+    from oracle import sam_vit
+    from ovmono3d_amd.util.synth_weights import SAM_ARCH, synth_sam_state_dict
+    arch = "vit_test"
+    D, L, heads, patch, M, ws, glob = SAM_ARCH[arch]
+    sd = synth_sam_state_dict(arch, seed=12)
+    cfg = SamVisionConfig(hidden_size=D, num_hidden_layers=L, num_attention_heads=heads, image_size=M * patch, patch_size=patch, window_size=ws,
+                          global_attn_indexes=list(glob), layer_norm_eps=1e-6, hidden_act="gelu", mlp_dim=4 * D, attn_implementation="eager")
+    x = torch.randn(2, 16, 16, D, generator=torch.Generator().manual_seed(0))
+    for i in (0, 1):                                                           # block 0 windowed, block 1 global
+        lyr = SamVisionLayer(cfg, window_size=0 if i in glob else ws).eval()
+        p = f"backbone.net.vit.blocks.{i}."
+        mapping = {"layer_norm1.weight": "norm1.weight", "layer_norm1.bias": "norm1.bias", "layer_norm2.weight": "norm2.weight",
+                   "layer_norm2.bias": "norm2.bias", "attn.qkv.weight": "attn.qkv.weight", "attn.qkv.bias": "attn.qkv.bias",
+                   "attn.proj.weight": "attn.proj.weight", "attn.proj.bias": "attn.proj.bias", "attn.rel_pos_h": "attn.rel_pos_h",
+                   "attn.rel_pos_w": "attn.rel_pos_w", "mlp.lin1.weight": "mlp.lin1.weight", "mlp.lin1.bias": "mlp.lin1.bias",
+                   "mlp.lin2.weight": "mlp.lin2.weight", "mlp.lin2.bias": "mlp.lin2.bias"}
+        params = dict(lyr.named_parameters())
+        assert set(params) == set(mapping), sorted(params)
+        with torch.no_grad():
+            for k, src in mapping.items():
+                assert params[k].shape == sd[p + src].shape, (k, params[k].shape, sd[p + src].shape)
+                params[k].copy_(sd[p + src])
+            o = lyr(x)
+            y_hf = o[0] if isinstance(o, (tuple, list)) else o
+        y = sam_vit.block(x, sd, p, heads, 0 if i in glob else ws)
+        assert float((y - y_hf).abs().max() / y_hf.abs().max()) < 2e-5, i
+    img = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(1))
+    out = sam_vit.sam_backbone_forward(sd, img, heads, L, ws, glob)
+    assert out.shape == (1, D, 16, 16) and torch.isfinite(out).all()
