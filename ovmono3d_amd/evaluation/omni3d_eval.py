@@ -315,13 +315,14 @@ class Omni3Deval:
 
     def summarize(self) -> Dict[str, float]:
         if self.mode == "2D":
-            keys = [("AP", None, "all"), ("AP50", 0.5, "all"), ("AP75", 0.75, "all"), ("APs", None, "small"), ("APm", None, "medium"),
-                    ("APl", None, "large")]
+            keys = [("AP", None, "all"), ("AP50", 0.5, "all"), ("AP75", 0.75, "all"), ("AP95", 0.95, "all"), ("APs", None, "small"),
+                    ("APm", None, "medium"), ("APl", None, "large")]
         else:
             keys = [("AP", None, "all"), ("AP15", 0.15, "all"), ("AP25", 0.25, "all"), ("AP50", 0.50, "all"), ("APn", None, "near"),
                     ("APm", None, "medium"), ("APf", None, "far")]
         out = {k: self._summarize(1, thr, rng) * 100 for k, thr, rng in keys}
-        out["AR100"] = self._summarize(0, None, "all", 100) * 100
+        for md in (1, 10, 100):                                                 # the reference's AR1 / AR10 / AR100 (:2190-2224)
+            out[f"AR{md}"] = self._summarize(0, None, "all", md) * 100
         if self.mode == "3D" and "average_nhd" in self.eval:
             for comp, v in self.eval["average_nhd"].items():
                 out["NHD" if comp == "overall" else f"NHD-{comp}"] = v
@@ -335,6 +336,21 @@ class Omni3Deval:
         out = {}
         for k, cid in enumerate(self.params.catIds):
             s = prec[:, :, k, 0, -1]
+            s = s[s > -1]
+            if isinstance(class_names, dict):
+                name = class_names.get(cid, cid)
+            else:
+                name = class_names[cid] if class_names is not None and cid < len(class_names) else cid
+            out[name] = float(np.mean(s) * 100) if s.size else float("nan")
+        return out
+
+    def per_category_ar(self, class_names=None) -> Dict:
+        """mean recall per category over the IoU thresholds at area 'all', maxDets 100 (the AR-<category> entries of the
+        reference's _derive_omni_results)."""
+        rec = self.eval["recall"]
+        out = {}
+        for k, cid in enumerate(self.params.catIds):
+            s = rec[:, k, 0, -1]
             s = s[s > -1]
             if isinstance(class_names, dict):
                 name = class_names.get(cid, cid)
@@ -368,6 +384,7 @@ def evaluate_omni3d(gts, dts: Sequence[Dict], device=None, only_2d: bool = False
     res["bbox_2D"] = e2.summarize()
     if names is not None:
         res["bbox_2D_per_category"] = e2.per_category_ap(names)
+        res["bbox_2D_per_category_AR"] = e2.per_category_ar(names)
     if not only_2d:
         d3 = [d for d in dts if "bbox3D" in d]
         e3 = Omni3Deval(gts, d3, "3D", device=device, fork_compat_2d_iou=fork_compat_2d_iou, img_ids=img_ids, cat_ids=cat_ids)
@@ -375,6 +392,7 @@ def evaluate_omni3d(gts, dts: Sequence[Dict], device=None, only_2d: bool = False
         res["bbox_3D"] = e3.summarize()
         if names is not None:
             res["bbox_3D_per_category"] = e3.per_category_ap(names)
+            res["bbox_3D_per_category_AR"] = e3.per_category_ar(names)
     return res
 
 
@@ -383,3 +401,39 @@ def omni3d_json_to_gt(dataset_json: Dict, filter_settings: Optional[Dict] = None
     see ``omni3d_gt.Omni3DGroundTruth`` for the rules."""
     from .omni3d_gt import Omni3DGroundTruth, filter_settings_from_cfg, ground_truth_records
     return ground_truth_records(Omni3DGroundTruth(dataset_json, filter_settings if filter_settings is not None else filter_settings_from_cfg(None)))
+
+
+# Omni3D's indoor / outdoor category groups (cubercnn/data/builtin.py:15-20: facts of the benchmark)
+OMNI3D_OUT = frozenset("pedestrian car cyclist van truck bus trailer motorcycle bicycle barrier".split() + ["traffic cone"])
+OMNI3D_IN = frozenset(["chair", "table", "cabinet", "lamp", "books", "sofa", "picture", "window", "pillow", "door", "blinds", "sink", "shelves",
+                       "television", "shoes", "cup", "bottle", "bookcase", "laptop", "desk", "floor mat", "mirror", "counter", "bicycle", "toilet", "bed",
+                       "refrigerator", "box", "oven", "clothes", "towel", "night stand", "stove", "machine", "stationery", "bathtub", "curtain", "bin"])
+OMNI3D_ALL = OMNI3D_OUT | OMNI3D_IN | frozenset(["camera", "cereal box"])      # the benchmark's 50 categories (builtin.py:12-14)
+
+
+def collective_summary(results: Dict) -> Dict:
+    """The cross-dataset numbers of the reference's ``Omni3DEvaluationHelper.summarize_all`` (:427-620) from ONE ``evaluate_omni3d`` result
+    over the concatenation of the datasets (re-accumulating the cached per-image results of every dataset, as the reference does, is the
+    same computation: a cell's matching depends on its own image and category only). ``<Concat>`` averages the per-category AP / AR
+    over the categories that have ground truth; ``Omni3D_Out`` / ``Omni3D_In`` / ``Omni3D`` over the benchmark's outdoor / indoor / all 50
+    categories, NaN unless every one of them was evaluated."""
+    def mean_over(table, cats):
+        vals = [table[c] for c in cats]
+        return float(np.mean(vals)) if vals and not any(np.isnan(v) for v in vals) else float("nan")
+    ap2, ar2 = results["bbox_2D_per_category"], results["bbox_2D_per_category_AR"]
+    ap3, ar3 = results.get("bbox_3D_per_category"), results.get("bbox_3D_per_category_AR")
+    have = {c for c, v in ap2.items() if not np.isnan(v)}
+    out = {"<Concat>": {"AP2D": mean_over(ap2, sorted(have)), "AR2D": mean_over(ar2, sorted(have)),
+                        "AP3D": mean_over(ap3, sorted(have)) if ap3 else float("nan"), "AR3D": mean_over(ar3, sorted(have)) if ar3 else float("nan")}}
+    if "bbox_3D" in results:
+        out["<Concat>"].update({"AP3D@15": results["bbox_3D"]["AP15"], "AP3D@25": results["bbox_3D"]["AP25"], "AP3D@50": results["bbox_3D"]["AP50"],
+                                "AP3D-N": results["bbox_3D"]["APn"], "AP3D-M": results["bbox_3D"]["APm"], "AP3D-F": results["bbox_3D"]["APf"]})
+        for k in ("NHD", "NHD-xy", "NHD-z", "NHD-dimensions", "NHD-pose"):
+            if k in results["bbox_3D"]:
+                out["<Concat>"][k] = results["bbox_3D"][k]
+    for label, group in (("Omni3D_Out", OMNI3D_OUT), ("Omni3D_In", OMNI3D_IN), ("Omni3D", OMNI3D_ALL)):
+        full = group <= have
+        out[label] = {"AP2D": mean_over(ap2, sorted(group)) if full else float("nan"), "AR2D": mean_over(ar2, sorted(group)) if full else float("nan"),
+                      "AP3D": mean_over(ap3, sorted(group)) if full and ap3 else float("nan"),
+                      "AR3D": mean_over(ar3, sorted(group)) if full and ar3 else float("nan")}
+    return out

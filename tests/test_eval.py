@@ -194,6 +194,44 @@ def test_category_map_and_ap_when_dataset_ids_differ_from_class_indices():
     assert [d["category_id"] for d in fork] == [0, 1, 3, 3]                     # index 3 ('d', id 4) taken for dataset id 3 ('c')
 
 
+def test_collective_summary_over_two_datasets():
+    """The cross-dataset numbers (reference summarize_all :427-620): one evaluation over the concatenated annotation files equals
+    accumulating the datasets together - a category that is perfect in dataset A and missed in dataset B ends at the AP of the
+    union, and the group means need every category of the group."""
+    from ovmono3d_amd.evaluation import (OMNI3D_ALL, OMNI3D_IN, OMNI3D_OUT, CategoryMap, Omni3DGroundTruth, collective_summary, evaluate_omni3d,
+                                         filter_settings_from_cfg)
+    assert len(OMNI3D_ALL) == 50 and len(OMNI3D_IN) == 38 and len(OMNI3D_OUT) == 11 and (OMNI3D_IN & OMNI3D_OUT) == {"bicycle"}
+    cats = ((11, "bicycle"), (18, "chair"))
+    ja = _omni_json([_omni_anno(1, 1, 18, "chair", [10, 20, 60, 120]), _omni_anno(2, 1, 11, "bicycle", [200, 50, 300, 250])], cats)
+    jb = _omni_json([_omni_anno(3, 1, 18, "chair", [30, 30, 130, 230])], cats)
+    for im in jb["images"]:
+        im["id"] += 10
+    jb["annotations"][0]["image_id"] += 10
+    fs = filter_settings_from_cfg(None)
+    fs.update(category_names=["chair", "bicycle"], trunc_2D_boxes=True)
+    gt = Omni3DGroundTruth([ja, jb], fs)
+    assert gt.image_ids == [1, 2, 11, 12] and len(gt) == 3
+    cm = CategoryMap.from_names(["chair", "bicycle"], ja["categories"])
+
+    def det(a, cls, score):
+        b = a["bbox2D_proj"]
+        return {"image_id": a["image_id"], "category_id": cls, "bbox": [b[0], b[1], b[2] - b[0], b[3] - b[1]], "score": score}
+    dts = [det(ja["annotations"][0], 1, 0.9), det(ja["annotations"][1], 0, 0.8)]          # dataset B's chair is missed
+    r = evaluate_omni3d(gt, dts, only_2d=True, category_map=cm)
+    assert abs(r["bbox_2D_per_category"]["bicycle"] - 100.0) < 1e-9 and abs(r["bbox_2D_per_category_AR"]["bicycle"] - 100.0) < 1e-9
+    assert abs(r["bbox_2D_per_category"]["chair"] - 100.0 * 51 / 101) < 1e-9            # 1 of 2 chairs found: recall points 0 .. 0.50
+    assert abs(r["bbox_2D_per_category_AR"]["chair"] - 50.0) < 1e-9
+    assert {"AP", "AP50", "AP75", "AP95", "APs", "APm", "APl", "AR1", "AR10", "AR100"} <= set(r["bbox_2D"])
+    c = collective_summary(r)
+    assert abs(c["<Concat>"]["AP2D"] - 0.5 * (100.0 + 100.0 * 51 / 101)) < 1e-9 and abs(c["<Concat>"]["AR2D"] - 75.0) < 1e-9
+    assert all(np.isnan(c[g]["AP2D"]) for g in ("Omni3D_Out", "Omni3D_In", "Omni3D"))     # groups need all of their categories
+    full = {"bbox_2D_per_category": {n: 50.0 for n in OMNI3D_ALL}, "bbox_2D_per_category_AR": {n: 60.0 for n in OMNI3D_ALL}}
+    full["bbox_2D_per_category"]["car"] = 94.0
+    cf = collective_summary(full)
+    assert abs(cf["Omni3D_Out"]["AP2D"] - (50.0 + 44.0 / 11)) < 1e-9 and cf["Omni3D_In"]["AP2D"] == 50.0 and abs(cf["Omni3D"]["AP2D"] - (50.0 + 44.0 / 50)) < 1e-9
+    assert cf["Omni3D"]["AR2D"] == 60.0 and np.isnan(cf["Omni3D"]["AP3D"])
+
+
 def test_nhd_known_values():
     from ovmono3d_amd.evaluation import cuboid_corners, disentangled_nhd, hungarian_distance
     gt = {"xy": [0.0, 0.0], "z": 5.0, "dimensions": [1.0, 2.0, 3.0], "pose": np.eye(3)}

@@ -29,8 +29,8 @@ from ovmono3d_amd.checkpoint import DetectionCheckpointer  # noqa: E402
 from ovmono3d_amd.data import (DatasetMapper3D, build_detection_test_loader, load_omni3d_json,  # noqa: E402
                                merge_oracle2d_to_detection_dicts)
 from ovmono3d_amd.defaults import make_cfg  # noqa: E402
-from ovmono3d_amd.evaluation import (CategoryMap, Omni3DEvaluator, Omni3DGroundTruth, eval_filter_settings,  # noqa: E402
-                                     evaluate_omni3d, inference_on_dataset)
+from ovmono3d_amd.evaluation import (CategoryMap, Omni3DEvaluator, Omni3DGroundTruth, collective_summary,  # noqa: E402
+                                     eval_filter_settings, evaluate_omni3d, inference_on_dataset)
 from ovmono3d_amd.evaluation.distributed import get_rank, get_world_size  # noqa: E402
 from ovmono3d_amd.modeling import build_model  # noqa: E402
 
@@ -59,6 +59,7 @@ def do_test(cfg, model, mode="base", datasets_root="datasets/Omni3D", image_root
     else:
         raise ValueError("wrong mode")
     out_dir = os.path.join(cfg.OUTPUT_DIR, "inference", "iter_final")
+    all_files, all_dets = [], []
     for name in names:
         dicts = load_omni3d_json(os.path.join(datasets_root, name + ".json"), image_root)
         if cfg.TEST.ORACLE2D:
@@ -79,6 +80,8 @@ def do_test(cfg, model, mode="base", datasets_root="datasets/Omni3D", image_root
             # do_test (tools/train_net.py:59-70), ground truth in DATASET category ids, detections un-mapped from the model's
             # contiguous class index (omni3d_evaluation.py:1029-1093)
             gt = Omni3DGroundTruth(os.path.join(datasets_root, name + ".json"), eval_filter_settings(cfg, mode))
+            all_files.append(os.path.join(datasets_root, name + ".json"))
+            all_dets += [inst for r in results for inst in r["instances"]]
             if len(gt):
                 cmap = category_map_for(cfg, mode, gt, category_meta)
                 ap = evaluate_omni3d(gt, [inst for r in results for inst in r["instances"]], category_map=cmap)
@@ -88,6 +91,18 @@ def do_test(cfg, model, mode="base", datasets_root="datasets/Omni3D", image_root
                     json.dump(cmap.to_meta(), f)
                 logger.info("%s: AP2D %.2f  AP3D %.2f  (AP3D@15 %.2f, @25 %.2f, @50 %.2f)  NHD %.4f", name, ap["bbox_2D"]["AP"],
                             ap["bbox_3D"]["AP"], ap["bbox_3D"]["AP15"], ap["bbox_3D"]["AP25"], ap["bbox_3D"]["AP50"], ap["bbox_3D"]["NHD"])
+
+
+    if get_rank() == 0 and len(all_files) > 1:
+        # the collective numbers of the reference's eval_helper.summarize_all (omni3d_evaluation.py:427-620): AP / AR over the union of the
+        # datasets' images, per category, and averaged over the Omni3D outdoor / indoor / all-50 category groups
+        gt = Omni3DGroundTruth(all_files, eval_filter_settings(cfg, mode))
+        if len(gt):
+            ap = evaluate_omni3d(gt, all_dets, category_map=category_map_for(cfg, mode, gt, category_meta))
+            ap["collective"] = collective_summary(ap)
+            with open(os.path.join(out_dir, "omni_ap_all.json"), "w") as f:
+                json.dump(ap, f)
+            logger.info("all %d datasets: %s", len(all_files), json.dumps(ap["collective"]))
 
 
 def category_map_for(cfg, mode, gt, category_meta=None):
