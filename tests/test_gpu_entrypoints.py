@@ -96,13 +96,20 @@ def test_eval_only_entry_point(device, tmp_path):
                                                  ("bicycle", "books", "bottle", "camera", "cereal box", "chair", "cup", "laptop", "shoes", "sofa"))]
     (root / "Omni3D" / "Objectron_test.json").write_text(json.dumps({"info": {"name": "Objectron"}, "images": images, "annotations": anns,
                                                                      "categories": cats}))
+    # a second dataset of the mode (its own image / annotation ids): the entry point then also writes the collective numbers
+    images2 = [dict(im, id=im["id"] + 100) for im in images[:2]]
+    anns2 = [dict(full, id=11, image_id=200, category_id=11, category_name="bicycle", bbox2D_proj=[10, 10, 90, 100])]
+    (root / "Omni3D" / "Toy_test.json").write_text(json.dumps({"info": {"name": "Toy"}, "images": images2, "annotations": anns2, "categories": cats}))
     out = tmp_path / "out"
     cmd = [sys.executable, os.path.join(ROOT, "tools", "train_net.py"), "--eval-only", "--config-file",
            os.path.join(ROOT, "configs", "OVMono3D_dinov2_SFP.yaml"), "--datasets-root", str(root / "Omni3D"), "--image-root", str(root),
            "MODEL.DINO.MODEL_NAME", "vittest14", "MODEL.FPN.SQUARE_PAD", "224", "INPUT.MIN_SIZE_TEST", "140", "INPUT.MAX_SIZE_TEST", "224",
-           "MODEL.WEIGHTS", "synthetic://vittest14?seed=3", "OUTPUT_DIR", str(out)]
+           "MODEL.WEIGHTS", "synthetic://vittest14?seed=3", "OUTPUT_DIR", str(out), "DATASETS.TEST_BASE", "('Objectron_test', 'Toy_test')"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+    both = json.loads((out / "inference" / "iter_final" / "omni_ap_all.json").read_text())
+    assert set(both["collective"]) == {"<Concat>", "Omni3D_Out", "Omni3D_In", "Omni3D"} and "AP3D" in both["collective"]["<Concat>"]
+    assert set(both["bbox_3D_per_category_AR"]) == set(both["bbox_2D_per_category"])
     res = json.loads((out / "inference" / "iter_final" / "Objectron_test" / "omni_instances_results.json").read_text())
     assert len(res) > 0 and {"image_id", "category_id", "bbox", "score", "bbox3D", "pose", "depth"} <= set(res[0])
     ap = json.loads((out / "inference" / "iter_final" / "Objectron_test" / "omni_ap.json").read_text())      # AP evaluator ran on the ground truth
