@@ -50,9 +50,10 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16"])
     ap.add_argument("--model", default="vitl14", help="DINOv2 arch (vitl14 ...) or, with --tower clip, an open_clip arch (ViT-B-16)")
-    ap.add_argument("--tower", default="dinov2", choices=["dinov2", "clip"],
-                    help="clip: the CLIP ViT-B/16 image tower config (BASELINE configs[3]; a parity-test case, not the headline): "
-                         "use --model ViT-B-16 --canvas 1024 --net-res 608 --proposals oracle2d")
+    ap.add_argument("--tower", default="dinov2", choices=["dinov2", "clip", "mae", "midas", "sam"],
+                    help="the other ViT towers of the reference's configs (parity-test cases, not the headline): clip = BASELINE configs[3], "
+                         "use --model ViT-B-16 --canvas 1024 --net-res 608 --proposals oracle2d; mae: --model facebook/vit-mae-base; "
+                         "midas: --model DPT_Large; sam: --model vit_b")
     ap.add_argument("--canvas", type=int, default=896)
     ap.add_argument("--net-res", type=int, default=532)
     ap.add_argument("--boxes", type=int, default=32, help="boxes per image for --proposals oracle2d")
@@ -79,7 +80,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
-    from common import build_cfg, build_clip_cfg, oracle_params
+    from common import build_cfg, build_clip_cfg, build_mae_cfg, build_midas_cfg, build_sam_cfg, oracle_params
     # experiment knobs of libovm3d (ovm_tune_set), e.g. OVM_TUNE=gdino_branches=0 - never set by the driver's runs
     from ovmono3d_amd import lib as _ovm_lib
     for kv in os.environ.get("OVM_TUNE", "").split(","):
@@ -88,12 +89,16 @@ def main():
             if _ovm_lib.load().ovm_tune_set(k.encode(), int(v)) != 0:
                 raise SystemExit(f"OVM_TUNE: unknown key {k!r}")
     from ovmono3d_amd.modeling import build_model
-    from ovmono3d_amd.util.synth_weights import CLIP_ARCH, VIT_ARCH, synth_state_dict
+    from ovmono3d_amd.util.synth_weights import CLIP_ARCH, MAE_ARCH, MIDAS_ARCH, SAM_ARCH, VIT_ARCH, synth_state_dict
 
-    clip = args.tower == "clip"
-    D, L, heads = CLIP_ARCH[args.model][:3] if clip else VIT_ARCH[args.model]
+    clip = args.tower != "dinov2"                        # any of the patch-16 towers behind the 4-level pyramid
+    arch_table = {"dinov2": VIT_ARCH, "clip": CLIP_ARCH, "mae": MAE_ARCH, "midas": MIDAS_ARCH, "sam": SAM_ARCH}[args.tower]
+    D, L, heads = arch_table[args.model][:3]
+    if args.tower == "mae":
+        L -= 1                                           # the reference taps the state before the last block (backbone/mae.py:43-55)
+    cfg_builder = {"dinov2": build_cfg, "clip": build_clip_cfg, "mae": build_mae_cfg, "midas": build_midas_cfg, "sam": build_sam_cfg}[args.tower]
     G = args.canvas // (16 if clip else 14)
-    T = G * G + 1
+    T = G * G + (0 if args.tower == "sam" else 1)
     B = args.batch
 
     def make_inputs(seed):
@@ -130,7 +135,7 @@ def main():
         gd_hf, gd_sd = synth_gdino_model(0)
 
     def run(precision, steps, warmup, profile):
-        cfg = (build_clip_cfg if clip else build_cfg)(args.model, args.canvas, precision, max_batch=B, max_rois=1000 if use_gdino else max(64, args.boxes),
+        cfg = cfg_builder(args.model, args.canvas, precision, max_batch=B, max_rois=1000 if use_gdino else max(64, args.boxes),
                         roi_heads="ROIHeads3DGDINO" if use_gdino else "ROIHeads3D",
                         extra=["MODEL.AMD.GDINO_CORUN", os.environ.get("OVM_BENCH_CORUN", "0") == "1"])
         model = build_model(cfg, device=dev)
@@ -224,6 +229,9 @@ def main():
                 "avg_launch_ms": round(avg_ms, 4), "launches": launches,
                 "algorithmic_flops_per_launch": flops_launch,
                 "mfma_passes_per_product": 3 if args.precision == "f16x3" else 1}
+    if args.tower == "sam":
+        roofline["note"] = ("the per-launch FLOP model assumes global attention over all T tokens; 8 of SAM's 12 blocks attend inside 14 x 14 "
+                            "windows and all of them run on the fp32-MFMA attention kernel: read `value`, not this fraction")
     if use_gdino:
         roofline["note"] = ("launch durations are measured while the GroundingDINO graph runs concurrently on a side stream "
                             "(the kernels share the CUs); --proposals oracle2d gives the uncontended figure")
@@ -396,7 +404,8 @@ def main():
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16x3" if args.precision == "f16x3" else "f16", "data": "synthetic",
-            "config": {"workload": ("CLIP image tower " if clip else "DINOv2 ") + f"{args.model} + SFP + "
+            "config": {"workload": {"dinov2": "DINOv2 ", "clip": "CLIP image tower ", "mae": "MAE encoder ", "midas": "MiDaS DPT ViT ",
+                                    "sam": "SAM image encoder "}[args.tower] + f"{args.model} + SFP + "
                                    + ("ROIHeads3DGDINO (native GroundingDINO Swin-B/BERT-base, 900 queries, 6 categories -> NMS)" if use_gdino
                                       else f"oracle-2D boxes ({args.boxes}/img)")
                                    + f" + ROIAlign + CubeHead + decode, batch {B}/GPU, 512x512 synthetic -> network res {args.net_res} "

@@ -5,7 +5,12 @@ O, P = os.path.join(R, "gpurun_out", "r02"), os.path.join(R, "profiles", "r02")
 os.makedirs(P, exist_ok=True)
 def last(f): return json.loads(open(os.path.join(O, f)).read().strip().splitlines()[-1])
 for src, dst in (("bench_final.json", "bench_r02_final.json"), ("bench_oracle2d.json", "bench_r02_oracle2d.json"),
-                 ("bench_oracle2d_b16.json", "bench_r02_oracle2d_b16.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json")):
+                 ("bench_oracle2d_b16.json", "bench_r02_oracle2d_b16.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"),
+                 ("bench_clip_b1.json", "bench_r02_clip_b1.json"), ("bench_mae_b1.json", "bench_r02_mae_b1.json"),
+                 ("bench_midas_b1.json", "bench_r02_midas_b1.json"), ("bench_sam_b1.json", "bench_r02_sam_b1.json"),
+                 ("bench_clip_b32.json", "bench_r02_clip_b32.json"), ("bench_c5_b64.json", "bench_r02_c5_b64.json")):
+    if not os.path.exists(os.path.join(O, src)):
+        continue
     json.dump(last(src), open(os.path.join(P, dst), "w"), indent=1)
 # kernel statistics: top 60 rows
 rows = open(os.path.join(O, "kernel_stats.csv")).read().splitlines()
