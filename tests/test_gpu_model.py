@@ -97,10 +97,13 @@ def test_depth_prompt(device):
     assert (out2[0]["instances"].pred_center_cam - out[0]["instances"].pred_center_cam).abs().max() > 0
 
 
-def test_fast_precision_runs(device):
-    """One-pass fp16 mode: same categories / box set, floats within the looser documented band."""
+@pytest.mark.parametrize("tower", ["dinov2", "clip", "mae", "midas", "sam"])
+def test_fast_precision_runs(device, tower):
+    """One-pass fp16 mode on every tower: same categories / box set, floats within the looser documented band."""
     from oracle.pipeline import inference
-    cfg = build_cfg("vittest14", 224, "f16", max_batch=1)
+    cfg = {"dinov2": lambda: build_cfg("vittest14", 224, "f16", max_batch=1), "clip": lambda: build_clip_cfg("ViT-test-16", 256, "f16", max_batch=1),
+           "mae": lambda: build_mae_cfg("test/vit-mae-test", 256, "f16", max_batch=1), "midas": lambda: build_midas_cfg("DPT_test", 256, "f16", max_batch=1),
+           "sam": lambda: build_sam_cfg("vit_test", 256, "f16", max_batch=1)}[tower]()
     model, sd = _build(cfg)
     inputs = synth_inputs(1, n_boxes=8, seed=7)
     out = model(inputs)
