@@ -19,6 +19,25 @@ namespace ovm {
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
+// Two probabilities -> packed fp16 hi parts and packed fp16 lo parts (lo = p - float(hi)) in four VALU instructions: packed convert,
+// two mixed-precision FMAs that read the fp16 halves directly (v_fma_mix_f32: p * 1.0 - hi, exact), packed convert. The compiler's
+// own code for `(half)p` / `(float)h` / `p - hf` / `(half)` spent seven (it converts to fp16 twice - scalar for the residual chain,
+// packed for the stored value - and back once): 48 fewer VALU instructions per key tile and wave.
+__device__ __forceinline__ void split2_pk(float p0, float p1, uint32_t& hp, uint32_t& lp) {
+  float d0, d1;
+  // p0 / p1 come straight out of v_exp_f32: the trans -> VALU wait state is the asm's own business (common.hpp, cvt_f16_rn)
+  asm("s_nop 0\n\tv_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(p0), "v"(p1));
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(d0) : "v"(p0), "v"(hp));
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d1) : "v"(p1), "v"(hp));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lp) : "v"(d0), "v"(d1));
+}
+__device__ __forceinline__ uint32_t cvt2_pk(float p0, float p1) {
+  uint32_t hp;
+  asm("s_nop 0\n\tv_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(p0), "v"(p1));
+  return hp;
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 template <int N> __device__ __forceinline__ void wait_vmcnt_n() {
   __builtin_amdgcn_s_waitcnt((N & 0xF) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
 }
@@ -180,7 +199,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const f32x2 shift2 = {kPShift - m_new, kPShift - m_new};
     f32x2 psum2 = {0.f, 0.f};
-    half8 ph[2][2], pl[2][2];
+    u32x4 phu[2][2], plu[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -195,13 +214,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
           // the fp16 subnormal range down to 3.7e-9 of the row maximum, so both parts can use the compiler's packed converts
           // (v_cvt_pk_f16_f32 flushes subnormal results): what a flush can drop is bounded by 4097 keys x 3.7e-9 (hi) and
           // 4097 x 7.6e-6 x 2^-11 (lo) of the largest term - 1.5e-5 each in the worst case.
-          const half_t h0 = (half_t)pv[0], h1 = (half_t)pv[1];
-          ph[i][sp][e] = h0; ph[i][sp][e + 1] = h1;
-          if (NPASS == 3) {
-            const f32x2 hf = {(float)h0, (float)h1};
-            const f32x2 pd = pv - hf;
-            pl[i][sp][e] = (half_t)pd[0]; pl[i][sp][e + 1] = (half_t)pd[1];
-          }
+          if (NPASS == 3) { uint32_t hp_, lp_; split2_pk(pv[0], pv[1], hp_, lp_); phu[i][sp][e >> 1] = hp_; plu[i][sp][e >> 1] = lp_; }
+          else phu[i][sp][e >> 1] = cvt2_pk(pv[0], pv[1]);
         }
       }
     const float psum = psum2[0] + psum2[1];
@@ -223,10 +237,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
           const half8 vh = *(const half8*)(vb + off);
           if (NPASS == 3) {
             const half8 vl = *(const half8*)(vb + PART + off);
-            o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[i][sp], o0[t], 0, 0, 0);
-            o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[i][sp], o0[t], 0, 0, 0);
+            o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, __builtin_bit_cast(half8, phu[i][sp]), o0[t], 0, 0, 0);
+            o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, __builtin_bit_cast(half8, plu[i][sp]), o0[t], 0, 0, 0);
           }
-          o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[i][sp], o0[t], 0, 0, 0);
+          o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, __builtin_bit_cast(half8, phu[i][sp]), o0[t], 0, 0, 0);
         }
     }
     if (!LAST) {
@@ -469,11 +483,10 @@ __global__ __launch_bounds__(512, 1) void attn_pp_kernel(const AttnParams p) {
           d += shift2;
           f32x2 pvv = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
           psum2 += pvv;
-          const half_t h0 = (half_t)pvv[0], h1 = (half_t)pvv[1];
-          ph[i][sp][e] = h0; ph[i][sp][e + 1] = h1;
-          const f32x2 hf = {(float)h0, (float)h1};
-          const f32x2 pd = pvv - hf;
-          pl[i][sp][e] = (half_t)pd[0]; pl[i][sp][e + 1] = (half_t)pd[1];
+          u32x4 hu_ = __builtin_bit_cast(u32x4, ph[i][sp]), lu_ = __builtin_bit_cast(u32x4, pl[i][sp]);
+          uint32_t hp_, lp_; split2_pk(pvv[0], pvv[1], hp_, lp_);
+          hu_[e >> 1] = hp_; lu_[e >> 1] = lp_;
+          ph[i][sp] = __builtin_bit_cast(half8, hu_); pl[i][sp] = __builtin_bit_cast(half8, lu_);
         }
       }
     const float psum = psum2[0] + psum2[1];
