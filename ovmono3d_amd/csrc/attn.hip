@@ -60,6 +60,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x >= p.main_blocks) { attn_tail_body<NPASS>(p, (int)blockIdx.x - p.main_blocks, smem); return; }
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  // diagnostic (ovm_debug_set_ptr "attn_stamps" with the lock-step kernel): every workgroup records its start / end s_memtime and its XCC id
+  const unsigned long long t_wg0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
   constexpr int PART = 64 * 128;                       // 64 rows x 128 B
   constexpr int SLOT = PART * ((NPASS == 3) ? 2 : 1);  // hi (+ lo)
   // Ring depth 3 for K and for V^T (96 KB: one workgroup per CU): two key tiles of LDS-DMA stay in flight and the end-of-tile
@@ -287,6 +289,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
         *(half4*)(p.Ohi + orow + oc) = hv;
         if (p.Olo) *(half4*)(p.Olo + orow + oc) = lv;
       }
+  }
+  if (p.stamps && tid == 0) {
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    p.stamps[3 * blockIdx.x] = t_wg0; p.stamps[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime(); p.stamps[3 * blockIdx.x + 2] = xcc;
   }
 }
 
