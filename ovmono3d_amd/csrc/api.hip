@@ -94,6 +94,8 @@ struct OvmHandle {
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   float *inf_boxes = nullptr, *inf_scores = nullptr; int *inf_classes = nullptr, *inf_n = nullptr, *inf_idx = nullptr, *inf_counts = nullptr;
   int inf_cap = 0;
+  void* inf_ws = nullptr; size_t inf_ws_bytes = 0;      // scratch of the GroundingDINO output glue (launch_gdino_post_ws)
+  int* inf_host = nullptr;                              // pinned: kept 2D count, record count
 };
 
 namespace {
@@ -379,6 +381,7 @@ int ovm_destroy(OvmHandle* h) {
   for (void* p : h->allocs) hipFree(p);
   if (h->h_imgs) hipHostFree(h->h_imgs);
   if (h->h_meta) hipHostFree(h->h_meta);
+  if (h->inf_host) hipHostFree(h->inf_host);
   for (int c = 0; c < OVM_PROF_NCAT; ++c)
     for (auto& pr : h->prof_ev[c]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -1142,21 +1145,36 @@ int ovm_infer(OvmHandle* h, OvmGdino* g, const OvmImage* image, const int32_t* t
   // backbone on the caller's stream
   r = ovm_backbone_forward(h, image, 1, nullptr, 0, 0, nullptr, nullptr, nullptr, stream);
   if (r) return r;
-  // join, output glue (synchronises the stream), cube head
+  // join, output glue (three launches on the handle's scratch), kept count to the host (the one synchronisation in front of the
+  // cube head, whose grid it sizes), cube head
   HCHECK(h, hipStreamWaitEvent(s, h->ev_join, 0));
   const float *logits = nullptr, *gboxes = nullptr; int ld = 0;
   r = ovm_gdino_last_outputs(g, &logits, &gboxes, &ld);
   if (r) { h->err = "detector outputs unavailable"; return r; }
-  r = ovm_gdino_postprocess(logits, nq, ld, gboxes, spans, n_phrases, image->height, image->width, box_threshold, nms_threshold, h->inf_boxes,
-                            h->inf_scores, h->inf_classes, h->inf_n, stream);
-  if (r) { h->err = "ovm_gdino_postprocess failed"; return r; }
-  int n2d = 0;
-  HCHECK(h, hipMemcpy(&n2d, h->inf_n, sizeof(int), hipMemcpyDeviceToHost));
+  if (nq <= 2048) {
+    const size_t need = gdino_post_ws_bytes(nq, n_phrases);
+    if (h->inf_ws_bytes < need) {
+      char* q = nullptr;
+      if ((r = dalloc(h, &q, need + need / 4))) return r;        // (the previous block stays in h->allocs until ovm_destroy)
+      h->inf_ws = q; h->inf_ws_bytes = need + need / 4;
+    }
+    r = launch_gdino_post_ws(logits, nq, ld, gboxes, spans, n_phrases, image->height, image->width, box_threshold, nms_threshold, h->inf_ws,
+                             h->inf_ws_bytes, h->inf_boxes, h->inf_scores, h->inf_classes, h->inf_n, s);
+  } else {
+    r = ovm_gdino_postprocess(logits, nq, ld, gboxes, spans, n_phrases, image->height, image->width, box_threshold, nms_threshold,
+                              h->inf_boxes, h->inf_scores, h->inf_classes, h->inf_n, stream);
+  }
+  if (r) { h->err = "GroundingDINO output glue failed (" + std::to_string(r) + ")"; return r; }
+  if (!h->inf_host) HCHECK(h, hipHostMalloc((void**)&h->inf_host, 2 * sizeof(int), hipHostMallocDefault));
+  HCHECK(h, hipMemcpyAsync(&h->inf_host[0], h->inf_n, sizeof(int), hipMemcpyDeviceToHost, s));
+  HCHECK(h, hipStreamSynchronize(s));
+  const int n2d = h->inf_host[0];
   if (n2d > out_capacity) { h->err = "output capacity too small"; return OVM_ERR_CAPACITY; }
   r = ovm_cube_forward(h, image, 1, h->inf_boxes, h->inf_scores, h->inf_classes, h->inf_idx, n2d, 1, out, h->inf_counts, stream);
   if (r) return r;
-  HCHECK(h, hipMemcpyAsync(n_out, h->inf_counts, sizeof(int), hipMemcpyDeviceToHost, s));
+  HCHECK(h, hipMemcpyAsync(&h->inf_host[1], h->inf_counts, sizeof(int), hipMemcpyDeviceToHost, s));
   HCHECK(h, hipStreamSynchronize(s));
+  *n_out = h->inf_host[1];
   return OVM_OK;
 }
 

@@ -621,12 +621,195 @@ __global__ void gdino_gather_kernel(const int* __restrict__ keep_idx, const int*
   for (int c = 0; c < 4; ++c) ob[i * 4 + c] = xyxy[q * 4 + c];
   os[i] = score[q]; oc[i] = cls[q];
 }
+// ---- the same glue as three launches on caller-owned scratch, no host round trip (nq <= 2048: the sort fits one workgroup) ----
+struct SpanArgs { int se[2 * kGdinoPostSpansByValue]; };
+
+// One workgroup: phrase scores of every query, (~score | query) keys, bitonic sort in LDS, boxes / scores / class indices gathered
+// in decreasing-score order (thresholded-out queries sort behind the valid ones and are dropped), *nvalid = number of valid queries.
+__global__ __launch_bounds__(1024) void gdino_post_sort_kernel(const float* __restrict__ logits, int nq, int ld,
+                                                               const float* __restrict__ cxcywh, const int* __restrict__ spans_dev,
+                                                               SpanArgs sa, int K, float img_h, float img_w, float thr, int N,
+                                                               float* __restrict__ sbox, float* __restrict__ sscore,
+                                                               int* __restrict__ scls, int* __restrict__ nvalid) {
+  __shared__ unsigned long long keys[2048];
+  __shared__ float sc[2048];
+  __shared__ int cl[2048];
+  const int t = threadIdx.x;
+  for (int q = t; q < N; q += 1024) {
+    unsigned long long key = kInvalidKey;
+    if (q < nq) {
+      const float* l = logits + (size_t)q * ld;
+      float best = -INFINITY; int arg = 0;
+      for (int k = 0; k < K; ++k) {
+        const int b0 = spans_dev ? spans_dev[2 * k] : sa.se[2 * k], b1 = spans_dev ? spans_dev[2 * k + 1] : sa.se[2 * k + 1];
+        float sum = 0.f;
+        for (int u = b0; u < b1; ++u) sum += 1.0f / (1.0f + expf(-l[u]));
+        if (sum > best) { best = sum; arg = k; }          // torch.max returns the first maximal index
+      }
+      sc[q] = best; cl[q] = arg;
+      if (K > 0 && best > thr) key = (((unsigned long long)(~ord32(best))) << 24) | (unsigned long long)q;
+    }
+    keys[q] = key;
+  }
+  __syncthreads();
+  for (int k = 2; k <= N; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int x = t; x < (N >> 1); x += 1024) {
+        const int i = ((x / j) * 2 * j) + (x % j), l2 = i + j;
+        const bool asc = ((i & k) == 0);
+        const unsigned long long a = keys[i], b = keys[l2];
+        if ((a > b) == asc) { keys[i] = b; keys[l2] = a; }
+      }
+      __syncthreads();
+    }
+  if (t == 0 && keys[0] == kInvalidKey) *nvalid = 0;
+  for (int pos = t; pos < N; pos += 1024) {
+    const unsigned long long key = keys[pos];
+    if (key == kInvalidKey) continue;
+    const int q = (int)(key & kIdMask);
+    // boxes * [w, h, w, h], then cxcywh -> xyxy, as separate roundings (roi_heads_gdino.py:253 and box_ops.box_cxcywh_to_xyxy)
+    const float cx = __fmul_rn(cxcywh[q * 4], img_w), cy = __fmul_rn(cxcywh[q * 4 + 1], img_h);
+    const float w = __fmul_rn(cxcywh[q * 4 + 2], img_w), h = __fmul_rn(cxcywh[q * 4 + 3], img_h);
+    sbox[pos * 4 + 0] = __fsub_rn(cx, __fmul_rn(0.5f, w)); sbox[pos * 4 + 1] = __fsub_rn(cy, __fmul_rn(0.5f, h));
+    sbox[pos * 4 + 2] = __fadd_rn(cx, __fmul_rn(0.5f, w)); sbox[pos * 4 + 3] = __fadd_rn(cy, __fmul_rn(0.5f, h));
+    sscore[pos] = sc[q]; scls[pos] = cl[q];
+    if (pos + 1 == N || keys[pos + 1] == kInvalidKey) *nvalid = pos + 1;
+  }
+}
+
+// mask[i*W + w] bit t  <=>  sorted candidate (w*64 + t) > i overlaps candidate i with IoU > thr; rows i < *nvalid only
+__global__ void nms_mask1_kernel(const float* __restrict__ sbox, const int* __restrict__ nvalid, int W, float thr,
+                                 unsigned long long* __restrict__ mask) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = *nvalid;
+  const int i = idx / W, w = idx - i * W;
+  if (i >= n) return;
+  unsigned long long bits = 0ull;
+  const int j0 = w * 64;
+  if (j0 + 63 > i && j0 < n) {
+    const float me[4] = {sbox[i * 4], sbox[i * 4 + 1], sbox[i * 4 + 2], sbox[i * 4 + 3]};
+    for (int u = 0; u < 64; ++u) {
+      const int j = j0 + u;
+      if (j > i && j < n && iou_gt(me, sbox + (size_t)j * 4, thr)) bits |= (1ull << u);
+    }
+  }
+  mask[(size_t)i * W + w] = bits;
+}
+
+// One workgroup: greedy pass over the sorted candidates in blocks of 64 - wave 0 settles a block from its 64 x 64 diagonal words
+// with scalar bit operations (only surviving candidates cost an iteration), all 16 waves OR the kept rows into the removed words
+// of the later blocks - then the kept candidates are emitted in order (boxes, scores, class indices, count).
+__global__ __launch_bounds__(1024) void nms_resolve_emit_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ nvalid,
+                                                                int W, const float* __restrict__ sbox, const float* __restrict__ sscore,
+                                                                const int* __restrict__ scls, float* __restrict__ ob,
+                                                                float* __restrict__ os, int* __restrict__ oc, int* __restrict__ n_out) {
+  __shared__ unsigned long long part[16][64];
+  __shared__ unsigned long long keptw[64];
+  __shared__ int pre[64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int n = *nvalid, nb = (n + 63) >> 6;
+  unsigned long long remv = 0ull;                                   // wave 0: lane w owns the removed word of block w
+  for (int b = 0; b < nb; ++b) {
+    if (wave == 0) {
+      const int row = 64 * b + lane;
+      const unsigned long long diag = row < n ? mask[(size_t)row * W + b] : 0ull;
+      const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+      const unsigned long long rw = __shfl(remv, b, 64);
+      unsigned long long alive = ~rw;
+      if (n - 64 * b < 64) alive &= (1ull << (n - 64 * b)) - 1ull;
+      unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)alive), ahi = __builtin_amdgcn_readfirstlane((unsigned)(alive >> 32));
+      unsigned klo = 0u, khi = 0u;
+      while (alo | ahi) {
+        const int u = alo ? (__builtin_ffs((int)alo) - 1) : (32 + __builtin_ffs((int)ahi) - 1);
+        if (u < 32) klo |= 1u << u; else khi |= 1u << (u - 32);
+        const unsigned slo = __builtin_amdgcn_readlane(dlo, u), shi = __builtin_amdgcn_readlane(dhi, u);
+        alo &= ~slo; ahi &= ~shi;
+        if (u < 32) alo &= ~(1u << u); else ahi &= ~(1u << (u - 32));
+      }
+      if (lane == 0) keptw[b] = ((unsigned long long)khi << 32) | klo;
+    }
+    __syncthreads();
+    const unsigned long long kept = keptw[b];
+    unsigned long long acc = 0ull;
+    if (lane < W && lane > b)
+      for (int r = wave; r < 64; r += 16)
+        if ((kept >> r) & 1ull) acc |= mask[(size_t)(64 * b + r) * W + lane];
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) remv |= part[v][lane];
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int b = 0; b < nb; ++b) { pre[b] = run; run += __popcll(keptw[b]); }
+    *n_out = run;
+  }
+  __syncthreads();
+  for (int pos = t; pos < n; pos += 1024) {
+    const unsigned long long kw = keptw[pos >> 6];
+    const int l = pos & 63;
+    if (!((kw >> l) & 1ull)) continue;
+    const int o = pre[pos >> 6] + __popcll(kw & ((1ull << l) - 1ull));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ob[o * 4 + c] = sbox[pos * 4 + c];
+    os[o] = sscore[pos]; oc[o] = scls[pos];
+  }
+}
 }  // namespace
+
+// scratch layout: sbox [N][4] f32 | sscore [N] f32 | scls [N] i32 | nvalid (16 B) | spans [2*K] i32 (only if K > by-value limit) | mask [nq][W] u64
+size_t gdino_post_ws_bytes(int nq, int K) {
+  if (nq <= 0 || nq > 2048) return 0;
+  const size_t N = nq <= 1024 ? 1024 : 2048, W = ((size_t)nq + 63) / 64;
+  const size_t sp = K > kGdinoPostSpansByValue ? (((size_t)2 * K * 4 + 15) & ~(size_t)15) : 0;
+  return N * 16 + N * 4 + N * 4 + 16 + sp + (size_t)nq * W * 8;
+}
+
+int launch_gdino_post_ws(const float* logits, int nq, int ld, const float* cxcywh, const int* spans, int K, int img_h, int img_w,
+                         float box_thr, float nms_thr, void* ws, size_t ws_bytes, float* out_boxes, float* out_scores, int* out_classes,
+                         int* n_out, hipStream_t s) {
+  if (nq == 0) return hipMemsetAsync(n_out, 0, sizeof(int), s) == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+  if (nq < 0 || nq > 2048 || K < 0 || !ws || ws_bytes < gdino_post_ws_bytes(nq, K)) return OVM_ERR_CAPACITY;
+  const int N = nq <= 1024 ? 1024 : 2048, W = (nq + 63) / 64;
+  char* p = (char*)ws;
+  float* sbox = (float*)p; p += (size_t)N * 16;
+  float* sscore = (float*)p; p += (size_t)N * 4;
+  int* scls = (int*)p; p += (size_t)N * 4;
+  int* nvalid = (int*)p; p += 16;
+  int* dsp = nullptr;
+  SpanArgs sa; memset(&sa, 0, sizeof(sa));
+  if (K > kGdinoPostSpansByValue) {
+    dsp = (int*)p; p += ((size_t)2 * K * 4 + 15) & ~(size_t)15;
+    if (hipMemcpyAsync(dsp, spans, sizeof(int) * 2 * K, hipMemcpyHostToDevice, s) != hipSuccess) return OVM_ERR_HIP;
+  } else if (K > 0) {
+    memcpy(sa.se, spans, sizeof(int) * 2 * K);
+  }
+  unsigned long long* mask = (unsigned long long*)p;
+  hipLaunchKernelGGL(gdino_post_sort_kernel, dim3(1), dim3(1024), 0, s, logits, nq, ld, cxcywh, (const int*)dsp, sa, K, (float)img_h,
+                     (float)img_w, box_thr, N, sbox, sscore, scls, nvalid);
+  hipLaunchKernelGGL(nms_mask1_kernel, dim3((unsigned)((nq * W + 127) / 128)), dim3(128), 0, s, sbox, nvalid, W, nms_thr, mask);
+  hipLaunchKernelGGL(nms_resolve_emit_kernel, dim3(1), dim3(1024), 0, s, mask, nvalid, W, sbox, sscore, scls, out_boxes, out_scores,
+                     out_classes, n_out);
+  return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
 
 int launch_gdino_post(const float* logits, int nq, int ld, const float* cxcywh, const int* spans, int K, int img_h, int img_w,
                       float box_thr, float nms_thr, float* out_boxes, float* out_scores, int* out_classes, int* n_out, hipStream_t s) {
   if (nq == 0) return hipMemsetAsync(n_out, 0, sizeof(int), s) == hipSuccess ? OVM_OK : OVM_ERR_HIP;
   if (nq < 0 || nq > 4096 || K < 0) return OVM_ERR_CAPACITY;
+  if (nq <= 2048) {                        // three launches on one scratch block
+    const size_t bytes = gdino_post_ws_bytes(nq, K);
+    void* ws = nullptr;
+    if (hipMalloc(&ws, bytes) != hipSuccess) return OVM_ERR_HIP;
+    int r = launch_gdino_post_ws(logits, nq, ld, cxcywh, spans, K, img_h, img_w, box_thr, nms_thr, ws, bytes, out_boxes, out_scores,
+                                 out_classes, n_out, s);
+    if (hipStreamSynchronize(s) != hipSuccess && !r) r = OVM_ERR_HIP;
+    (void)hipFree(ws);
+    return r;
+  }
   std::vector<void*> tmp;
   float *xyxy = nullptr, *score = nullptr; int *cls = nullptr, *valid = nullptr, *keep = nullptr, *dsp = nullptr;
   int r;

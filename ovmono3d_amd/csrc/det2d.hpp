@@ -58,6 +58,13 @@ int det2d_forward(const Det2dModel& m, Det2dWorkspace& w, float* boxes, float* s
 int launch_nms_single(const float* boxes, const float* scores, const int* valid, int n, float thresh, int* keep_idx, int* n_keep,
                       hipStream_t s);
 int launch_topk(const float* scores, int n, int k, int* out_idx, hipStream_t s);
+// GroundingDINO output glue without a host round trip: three launches on caller-owned scratch (gdino_post_ws_bytes; nq <= 2048), nothing
+// allocated, nothing synchronised; up to kGdinoPostSpansByValue phrase spans travel as kernel arguments.
+constexpr int kGdinoPostSpansByValue = 128;
+size_t gdino_post_ws_bytes(int nq, int K);
+int launch_gdino_post_ws(const float* logits, int nq, int ld, const float* cxcywh, const int* spans, int K, int img_h, int img_w,
+                         float box_thr, float nms_thr, void* ws, size_t ws_bytes, float* out_boxes, float* out_scores, int* out_classes,
+                         int* n_out, hipStream_t s);
 int launch_gdino_post(const float* logits, int nq, int ld, const float* cxcywh, const int* spans, int K, int img_h, int img_w,
                       float box_thr, float nms_thr, float* out_boxes, float* out_scores, int* out_classes, int* n_out, hipStream_t s);
 

@@ -288,6 +288,31 @@ def test_gdino_glue_matches_oracle(device):
     assert_close(s, rs, 1e-5, "gdino scores")
 
 
+@pytest.mark.parametrize("nq,ncat,crowd", [(900, 6, 0.08), (1500, 140, 0.3), (2048, 3, 0.02), (64, 2, 0.5), (3000, 5, 0.1)])
+def test_gdino_glue_shapes_and_paths(device, nq, ncat, crowd):
+    """The glue's three-launch form (one-workgroup sort, bit-matrix, blocked greedy pass) against the oracle on crowded scenes:
+    more than 1024 queries (2048-key sort), more phrases than travel as kernel arguments (device span table), a sort that is
+    exactly full, fewer queries than one block, and nq > 2048 (the multi-kernel route). Then: no query above the threshold."""
+    from oracle.gdino_glue import gdino_postprocess as ref_post
+    from ovmono3d_amd.modeling.roi_heads.gdino_glue import gdino_postprocess
+    g = torch.Generator().manual_seed(nq + ncat)
+    ld = 2 * ncat + 2
+    spans = [(1 + 2 * i, 2 + 2 * i) for i in range(ncat)]          # single-token phrases separated by '.'
+    cats = [f"c{i}" for i in range(ncat)]
+    logits = torch.randn(nq, ld, generator=g) * 3 - 3
+    logits[::5] -= 12                                              # a fifth of the queries fall under the 0.001 threshold
+    centres = torch.rand(nq, 2, generator=g)
+    boxes = torch.cat([centres, crowd * (0.5 + torch.rand(nq, 2, generator=g))], dim=1)
+    rb, rs, rc = ref_post(logits, boxes, spans, cats, [[c] for c in cats], (480, 640))
+    b, s, c = gdino_postprocess(logits.to(device), boxes.to(device), spans, (480, 640))
+    assert 4 < len(rs) < int(0.8 * nq) and len(rs) == len(s), (len(rs), len(s))
+    assert torch.equal(c.cpu(), rc)
+    assert_close(b, rb, 1e-6, "gdino boxes")
+    assert_close(s, rs, 1e-5, "gdino scores")
+    b, s, c = gdino_postprocess((logits - 40).to(device), boxes.to(device), spans, (480, 640))
+    assert len(s) == 0 and len(b) == 0
+
+
 @pytest.mark.parametrize("M,N,K,ksplit", [(256, 256, 64, 1), (300, 512, 96, 1), (4097, 768, 256, 1), (1024, 256, 1024, 4), (700, 512, 2048, 8),
                                           (512, 256, 32, 1)])
 def test_gemm256_two_wave_group_kernel(device, M, N, K, ksplit):
