@@ -46,20 +46,25 @@ def do_test(args, cfg, model):
     if bool(cfg.MODEL.AMD.get("GPU_RESIZE", False)):
         from ovmono3d_amd.data.gpu_resize import ResizeShortestEdgeGPU
         gpu_resize = ResizeShortestEdgeGPU(cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
+    gpu_jpeg = gpu_resize is not None and bool(cfg.MODEL.AMD.get("GPU_JPEG", False))
     use_gdino_head = cfg.MODEL.ROI_HEADS.NAME == "ROIHeads3DGDINO"
     for name in ims:
         im_name = os.path.splitext(name)[0]
         cats = cats_per_img.get(im_name, [])
         if cats == []:
             continue
-        im = read_image(os.path.join(args.input_folder, name), "BGR")       # cv2.imread order, demo.py:52
+        if gpu_jpeg:                                                         # baseline JPEG: host entropy decode, pixels born on the device
+            from ovmono3d_amd.data.gpu_jpeg import read_image_device
+            im = read_image_device(os.path.join(args.input_folder, name), "BGR", torch.device("cuda"))
+        else:
+            im = read_image(os.path.join(args.input_folder, name), "BGR")   # cv2.imread order, demo.py:52
         h, w = im.shape[:2]
         if focal_length == 0:
             focal_length = 4.0 * h / 2                                       # demo.py:63-65
         px, py = (w / 2, h / 2) if len(principal_point) == 0 else principal_point
         K = np.array([[focal_length, 0.0, px], [0.0, focal_length, py], [0.0, 0.0, 1.0]])
         if gpu_resize is not None:                                           # device-side ResizeShortestEdge, bit-identical to Pillow's
-            image_t = gpu_resize(torch.from_numpy(np.ascontiguousarray(im)).cuda()).permute(2, 0, 1)
+            image_t = gpu_resize(im if torch.is_tensor(im) else torch.from_numpy(np.ascontiguousarray(im)).cuda()).permute(2, 0, 1)
         else:
             image_t = torch.as_tensor(np.ascontiguousarray(resize(im).transpose(2, 0, 1)))
         d = {"image": image_t, "height": h, "width": w, "K": K}

@@ -29,6 +29,7 @@ extern "C" {
 #define OVM_ERR_MISSING_WEIGHT (-3)
 #define OVM_ERR_SHAPE (-4)
 #define OVM_ERR_CAPACITY (-5)
+#define OVM_ERR_UNSUPPORTED (-6) /* a valid input outside the documented scope of the call (e.g. a progressive JPEG) */
 
 #define OVM_REC_FLOATS 48 /* detection record width, see OvmDet3D */
 
@@ -373,6 +374,30 @@ int ovm_resize_bilinear_u8(const uint8_t* src, int32_t H, int32_t W, int32_t C, 
  * mapper applies it to a depth prompt (cubercnn/data/dataset_mapper.py:45-52 to the image size, :70-72 through ResizeShortestEdge
  * - detectron2's ResizeTransform takes this route for non-uint8 arrays). src [B][H][W] dense, dst [B][outH][outW], device. */
 int ovm_resize_bilinear_f32(const float* src, int32_t B, int32_t H, int32_t W, int32_t outH, int32_t outW, float* dst, ovm_stream_t stream);
+
+/* JPEG decode split at its only serial step. The reference reads images with cv2.imread (demo/demo.py:52) and detectron2's
+ * read_image = Pillow (cubercnn/data/dataset_mapper.py:38), both libjpeg-turbo at its defaults (JDCT_ISLOW, fancy upsampling,
+ * integer YCbCr -> RGB). ovm_host_jpeg_info walks the headers; ovm_host_jpeg_entropy_decode Huffman-decodes every scan on the
+ * host into coefficient planes (int16 [coef_blocks][64] in natural order, component after component, each plane bw x bh blocks =
+ * whole MCUs); ovm_jpeg_reconstruct dequantises, runs the 8 x 8 inverse DCT, upsamples the chroma and converts the colours on the
+ * device into rgb [height][width][3] (planes: device scratch of coef_blocks * 64 bytes). Bit-identical to libjpeg-turbo / Pillow
+ * `Image.open(f).convert("RGB")`. Scope: 8-bit baseline / extended-sequential Huffman JPEGs, grey or 3 components with luma
+ * sampling 1x1 / 2x1 / 2x2; anything else (progressive, arithmetic, 12-bit, CMYK) -> OVM_ERR_UNSUPPORTED from the two host
+ * calls, a corrupt stream -> OVM_ERR_INVALID. */
+typedef struct OvmJpegInfo {
+  int32_t width, height, ncomp;   /* ncomp 1 or 3 */
+  int32_t hmax, vmax;             /* luma sampling factors (chroma is 1 x 1) */
+  int32_t h[3], v[3];
+  int32_t bw[3], bh[3];           /* coefficient plane of each component, in blocks */
+  int32_t cw[3], ch[3];           /* component size in samples (ceil(width * h / hmax), ...) */
+  int32_t qidx[3];
+  int32_t colorspace;             /* 0 grey, 1 YCbCr, 2 RGB (no transform) */
+  int32_t coef_blocks;            /* sum of bw * bh */
+  uint16_t qt[4][64];             /* quantisation tables, natural order */
+} OvmJpegInfo;
+int ovm_host_jpeg_info(const uint8_t* data, size_t n, OvmJpegInfo* info);
+int ovm_host_jpeg_entropy_decode(const uint8_t* data, size_t n, int16_t* coef, int64_t coef_capacity, OvmJpegInfo* info);
+int ovm_jpeg_reconstruct(const int16_t* coef, const OvmJpegInfo* info, uint8_t* planes, uint8_t* rgb, ovm_stream_t stream);
 
 #ifdef __cplusplus
 }

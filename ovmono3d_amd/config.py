@@ -305,6 +305,7 @@ def get_cfg_defaults(cfg: CfgNode) -> CfgNode:
                                  GDINO_CORUN=False,
                                  # one image + category_list: the whole path as ONE C call (ovm_infer) instead of staged calls from Python
                                  FUSED_INFER=True,
+                                 # GPU_JPEG: baseline JPEGs are entropy-decoded on the host and reconstructed on the device (data/gpu_jpeg.py)
                                  # ResizeShortestEdge on the device (bit-identical to the host's Pillow resize)
-                                 GPU_RESIZE=True))
+                                 GPU_RESIZE=True, GPU_JPEG=True))
     return cfg

@@ -370,6 +370,7 @@ int ovm_abi_sizeof(const char* name) {
   if (n == "OvmImage") return (int)sizeof(OvmImage);
   if (n == "OvmDet3D") return (int)sizeof(OvmDet3D);
   if (n == "OvmGdinoConfig") return (int)sizeof(OvmGdinoConfig);
+  if (n == "OvmJpegInfo") return (int)sizeof(OvmJpegInfo);
   return -1;
 }
 

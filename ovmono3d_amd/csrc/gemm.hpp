@@ -700,6 +700,7 @@ int launch_gemm_small_ex(const float* A, const float* A2, int lda, int M, int K,
                          hipStream_t s);
 void gemm_small_set(int target_blocks, int max_ksplit);
 void gemm_small_set_stages(int n);
+void gemm_small_set_wpe(int n);
 void glinear_set_small_max_tiles(int t);
 void gbmm_set_tiled(int v);
 

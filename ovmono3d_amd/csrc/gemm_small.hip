@@ -46,8 +46,10 @@ __device__ __forceinline__ void cvt8(const float4 a, const float4 b, half8& h, h
   l = (half8){l0, l1, l2, l3, l4, l5, l6, l7};
 }
 
-template <int NPASS, int NSTAGE>
-__global__ __launch_bounds__(256) void gemm_f32a_kernel(const SmallGemmParams p) {
+// WPE = waves per SIMD the register allocation is held to: 4 (<= 128 VGPRs) lets a workgroup take the slots the ViT's attention
+// workgroups leave free on a CU (128 VGPRs per SIMD, 64 KB of LDS) instead of waiting for one of them to retire.
+template <int NPASS, int NSTAGE, int WPE = 1>
+__global__ __launch_bounds__(256, WPE) void gemm_f32a_kernel(const SmallGemmParams p) {
   constexpr int PARTS = (NPASS == 3) ? 4 : 2;
   constexpr int PART = 64 * 128;                                    // 64 rows x 64 halves
   constexpr int P_AH = 0, P_AL = PART, P_WH = (NPASS == 3 ? 2 : 1) * PART, P_WL = 3 * PART;
@@ -237,11 +239,13 @@ __global__ void splitk_reduce_kernel(const SmallGemmParams p) {
 namespace {
 int g_target_blocks = 512;     // split K until the grid has about this many workgroups
 int g_max_ksplit = 16;
+int g_wpe = 1;
 int g_stages = 1;        // single LDS buffer: 32 KB per workgroup, more workgroups per CU (measured faster on these shapes)
 struct Ws { float* p = nullptr; size_t cap = 0; } g_ws;
 }  // namespace
 
 void gemm_small_set_stages(int n) { g_stages = (n == 1) ? 1 : 2; }
+void gemm_small_set_wpe(int n) { g_wpe = (n >= 4) ? 4 : 1; }
 void gemm_small_set(int target_blocks, int max_ksplit) {
   if (target_blocks >= 0) g_target_blocks = target_blocks;
   if (max_ksplit >= 1) g_max_ksplit = max_ksplit;
@@ -300,7 +304,8 @@ int launch_gemm_small_ex(const float* A, const float* A2, int lda, int M, int K,
     if (npass == 3) hipLaunchKernelGGL((gemm_f32a_kernel<3, 2>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_f32a_kernel<1, 2>), grid, dim3(256), 0, s, p);
   } else {
-    if (npass == 3) hipLaunchKernelGGL((gemm_f32a_kernel<3, 1>), grid, dim3(256), 0, s, p);
+    if (npass == 3 && g_wpe == 4) hipLaunchKernelGGL((gemm_f32a_kernel<3, 1, 4>), grid, dim3(256), 0, s, p);
+    else if (npass == 3) hipLaunchKernelGGL((gemm_f32a_kernel<3, 1>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_f32a_kernel<1, 1>), grid, dim3(256), 0, s, p);
   }
   if (ksplit > 1) {

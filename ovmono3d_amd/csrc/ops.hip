@@ -201,6 +201,7 @@ int ovm_tune_set(const char* key, int32_t value) {
   if (!strcmp(key, "glin_target_blocks")) { gemm_small_set(value, -1); return OVM_OK; }
   if (!strcmp(key, "gbmm_tiled")) { gbmm_set_tiled(value); return OVM_OK; }
   if (!strcmp(key, "glin_stages")) { gemm_small_set_stages(value); return OVM_OK; }
+  if (!strcmp(key, "glin_wpe")) { gemm_small_set_wpe(value); return OVM_OK; }
   if (!strcmp(key, "glin_max_ksplit")) { gemm_small_set(-1, value); return OVM_OK; }
   if (!strcmp(key, "gemm256")) { ovm::set_use_gemm256(value); return OVM_OK; }          // engine: 256 x 256 kernel for qkv / fc1 (default 1)
   if (!strcmp(key, "op_gemm256")) { g_op_gemm256 = value; return OVM_OK; }

@@ -1,6 +1,7 @@
-"""Host-side data feeding for the entry points (JPEG decode, ResizeShortestEdge, Omni3D JSON, oracle-2D merge,
-contiguous per-rank shards). This is NOT on the GPU hot path and is deliberately plain host code
-(SURVEY.md §8f row 2 lists a GPU resize as a "next" step); its OUTPUT schema is the hot path's input
+"""Data feeding for the entry points (image read, ResizeShortestEdge, Omni3D JSON, oracle-2D merge, contiguous per-rank
+shards). With a HIP device the pixel work runs there: baseline JPEGs are reconstructed on the device from
+host-decoded coefficients (gpu_jpeg.py), ``ResizeShortestEdge`` and the depth-prompt resizes are device kernels (gpu_resize.py);
+the plain host code below is what the entry points use without one. The OUTPUT schema is the hot path's input
 contract: per image ``{"image": uint8 CHW, "height", "width", "K", "image_id", ["oracle2D"], ["depth"]}``
 (reference cubercnn/data/dataset_mapper.py:33-80, cubercnn/data/build.py:45-54,281-311, demo/demo.py:46-85).
 """
@@ -101,10 +102,16 @@ class DatasetMapper3D:
             from .gpu_resize import DepthPromptResizeGPU, ResizeShortestEdgeGPU
             self.gpu_resize = ResizeShortestEdgeGPU(cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
             self.gpu_depth_resize = DepthPromptResizeGPU(cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
+        # baseline JPEGs reconstructed on the device from host-decoded coefficients (gpu_jpeg.py; bit-identical to the Pillow read)
+        self.gpu_jpeg = self.gpu_resize is not None and bool(cfg.MODEL.AMD.get("GPU_JPEG", False))
 
     def __call__(self, d: Dict) -> Dict:
         d = dict(d)
-        image = read_image(d["file_name"], self.image_format)
+        if self.gpu_jpeg:
+            from .gpu_jpeg import read_image_device
+            image = read_image_device(d["file_name"], self.image_format, torch.device("cuda"))      # uint8 [H, W, 3] in HBM
+        else:
+            image = read_image(d["file_name"], self.image_format)
         depth = None
         if self.use_depth:
             base = os.path.splitext(os.path.basename(d["file_name"]))[0]
@@ -113,17 +120,18 @@ class DatasetMapper3D:
                 if self.gpu_resize is not None:
                     pass                                                       # both resizes run on the device below
                 elif depth.shape[:2] != image.shape[:2]:
-                    depth = torch.nn.functional.interpolate(torch.from_numpy(depth)[None, None], size=image.shape[:2],
+                    depth = torch.nn.functional.interpolate(torch.from_numpy(depth)[None, None], size=tuple(image.shape[:2]),
                                                             mode="bilinear", align_corners=False)[0, 0].numpy()
             except Exception:
-                depth = np.zeros(image.shape[:2], dtype=np.float32)
+                depth = np.zeros(tuple(image.shape[:2]), dtype=np.float32)
         if self.gpu_resize is not None:
-            d["image"] = self.gpu_resize(torch.from_numpy(np.ascontiguousarray(image)).cuda()).permute(2, 0, 1)   # CHW view of the HWC result
+            dev_img = image if torch.is_tensor(image) else torch.from_numpy(np.ascontiguousarray(image)).cuda()
+            d["image"] = self.gpu_resize(dev_img).permute(2, 0, 1)   # CHW view of the HWC result
         else:
             image = self.resize(image)
             d["image"] = torch.as_tensor(np.ascontiguousarray(image.transpose(2, 0, 1)))
         if depth is not None and self.gpu_resize is not None:
-            d["depth"] = self.gpu_depth_resize(torch.from_numpy(np.ascontiguousarray(depth)).cuda(), image.shape[:2]).unsqueeze(0)
+            d["depth"] = self.gpu_depth_resize(torch.from_numpy(np.ascontiguousarray(depth)).cuda(), tuple(image.shape[:2])).unsqueeze(0)
         elif depth is not None:
             d["depth"] = torch.as_tensor(np.ascontiguousarray(self.resize(depth))).unsqueeze(0)
         return d

@@ -59,6 +59,16 @@ class OvmGdinoConfig(C.Structure):
     ]
 
 
+class OvmJpegInfo(C.Structure):
+    """Mirror of include/ovm3d.h OvmJpegInfo."""
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("ncomp", C.c_int32), ("hmax", C.c_int32), ("vmax", C.c_int32),
+        ("h", C.c_int32 * 3), ("v", C.c_int32 * 3), ("bw", C.c_int32 * 3), ("bh", C.c_int32 * 3), ("cw", C.c_int32 * 3),
+        ("ch", C.c_int32 * 3), ("qidx", C.c_int32 * 3), ("colorspace", C.c_int32), ("coef_blocks", C.c_int32),
+        ("qt", (C.c_uint16 * 64) * 4),
+    ]
+
+
 EXPORTS = [
     "ovm_create", "ovm_destroy", "ovm_last_error", "ovm_version", "ovm_abi_sizeof", "ovm_backbone_forward", "ovm_cube_forward",
     "ovm_rpn_box_forward", "ovm_gather_records", "ovm_gather_counts", "ovm_host_interp_pos_embed", "ovm_host_resize_pos_embed_aa", "ovm_host_sincos_pos_embed", "ovm_host_shard_range",
@@ -70,6 +80,7 @@ EXPORTS = [
     "ovm_g_groupnorm", "ovm_g_msdeform", "ovm_g_sine_embed", "ovm_g_normalize_image", "ovm_g_topk", "ovm_g_rowmax",
     "ovm_gdino_create", "ovm_gdino_destroy", "ovm_gdino_last_error", "ovm_gdino_forward", "ovm_gdino_detect", "ovm_gdino_set_force_topk",
     "ovm_gdino_debug_copy", "ovm_debug_set_ptr", "ovm_gdino_num_queries", "ovm_gdino_last_outputs", "ovm_infer",
+    "ovm_host_jpeg_info", "ovm_host_jpeg_entropy_decode", "ovm_jpeg_reconstruct",
 ]
 PROF_NAMES = ("attn", "qkv", "proj", "fc1", "fc2", "ln")
 
@@ -93,10 +104,14 @@ def load() -> C.CDLL:
     lib.ovm_last_error.restype = C.c_char_p
     lib.ovm_version.restype = C.c_char_p
     lib.ovm_abi_sizeof.argtypes = [C.c_char_p]
-    for name, mirror in (("OvmConfig", OvmConfig), ("OvmTensor", OvmTensor), ("OvmImage", OvmImage), ("OvmGdinoConfig", OvmGdinoConfig)):
+    for name, mirror in (("OvmConfig", OvmConfig), ("OvmTensor", OvmTensor), ("OvmImage", OvmImage), ("OvmGdinoConfig", OvmGdinoConfig),
+                         ("OvmJpegInfo", OvmJpegInfo)):
         if lib.ovm_abi_sizeof(name.encode()) != C.sizeof(mirror):
             raise RuntimeError(f"{LIB_PATH}: sizeof({name}) = {lib.ovm_abi_sizeof(name.encode())} but the ctypes mirror has "
                                f"{C.sizeof(mirror)} bytes - rebuild the library (ovmono3d_amd/csrc/build.sh) or update lib.py")
+    lib.ovm_host_jpeg_info.argtypes = [vp, C.c_size_t, C.POINTER(OvmJpegInfo)]
+    lib.ovm_host_jpeg_entropy_decode.argtypes = [vp, C.c_size_t, vp, i64, C.POINTER(OvmJpegInfo)]
+    lib.ovm_jpeg_reconstruct.argtypes = [vp, C.POINTER(OvmJpegInfo), vp, vp, vp]
     lib.ovm_backbone_forward.argtypes = [vp, C.POINTER(OvmImage), i32, vp, i32, i32, vp, vp, vp, vp]
     lib.ovm_cube_forward.argtypes = [vp, C.POINTER(OvmImage), i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
     lib.ovm_rpn_box_forward.argtypes = [vp, C.POINTER(OvmImage), i32, vp, vp, vp, vp, vp, vp, vp]

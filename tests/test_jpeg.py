@@ -1,0 +1,129 @@
+"""JPEG decode split between the host (entropy decode) and the device (reconstruction): SURVEY.md 8f row 2.
+
+The oracle is the reference's own decoder, live: Pillow = libjpeg-turbo, which is also what cv2.imread links (reference
+demo/demo.py:52, cubercnn/data/dataset_mapper.py:38). CPU tests pin the host entropy decoder and the numpy restatement
+(oracle/jpeg_ref.py) against Pillow bit for bit; the GPU test pins the device reconstruction the same way."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from ovmono3d_amd.data import gpu_jpeg
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+COCO = os.path.join(HERE, "golden", "coco_000000101762.jpg")          # data fixture: one of the reference's demo inputs
+
+
+def _scene(h, w, seed):
+    """A smooth scene with edges and noise, so every frequency band and the chroma filters get exercised."""
+    g = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.stack([127 + 120 * np.sin(xx / 9.0 + seed) * np.cos(yy / 13.0), 127 + 120 * np.sin((xx + yy) / 17.0),
+                    255.0 * ((xx // 16 + yy // 12) % 2)], axis=-1)
+    img += g.normal(0, 12, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def _jpeg(arr, **kw):
+    b = io.BytesIO()
+    Image.fromarray(arr).save(b, format="JPEG", **kw)
+    return b.getvalue()
+
+
+def _pil(data):
+    with Image.open(io.BytesIO(data)) as im:
+        return np.asarray(im.convert("RGB"))
+
+
+CASES = [
+    ("444_q90", (61, 83), dict(quality=90, subsampling=0)),
+    ("422_q75", (64, 97), dict(quality=75, subsampling=1)),
+    ("420_q75", (75, 101), dict(quality=75, subsampling=2)),
+    ("420_q30_optimised_tables", (200, 333), dict(quality=30, subsampling=2, optimize=True)),
+    ("420_q100", (48, 64), dict(quality=100, subsampling=2)),
+    ("420_tiny_width", (9, 3), dict(quality=85, subsampling=2)),          # downsampled width 2: plain replication
+    ("422_tiny_width", (5, 4), dict(quality=85, subsampling=1)),
+    ("420_one_pixel", (1, 1), dict(quality=85, subsampling=2)),
+    ("420_restart_rows", (130, 170), dict(quality=80, subsampling=2, restart_marker_rows=1)),
+    ("444_restart_blocks", (40, 90), dict(quality=80, subsampling=0, restart_marker_blocks=3)),
+    ("420_q5_16bit_tables", (64, 64), dict(quality=1, subsampling=2)),
+]
+
+
+def _case_bytes(name, hw, kw):
+    arr = _scene(hw[0], hw[1], len(name))
+    return _jpeg(arr, **kw)
+
+
+@pytest.mark.parametrize("name,hw,kw", CASES, ids=[c[0] for c in CASES])
+def test_host_entropy_decode_and_restatement_equal_pillow(name, hw, kw):
+    from oracle import jpeg_ref
+    data = _case_bytes(name, hw, kw)
+    coef, info = gpu_jpeg.entropy_decode(data)
+    assert (info.height, info.width) == hw and info.ncomp == 3
+    out = jpeg_ref.reconstruct(coef.numpy(), info)
+    assert np.array_equal(out, _pil(data))
+
+
+def test_grey_and_coco_example_equal_pillow():
+    from oracle import jpeg_ref
+    grey = _jpeg(_scene(77, 53, 3)[:, :, 0], quality=80)
+    coef, info = gpu_jpeg.entropy_decode(grey)
+    assert info.ncomp == 1 and info.colorspace == 0
+    assert np.array_equal(jpeg_ref.reconstruct(coef.numpy(), info), _pil(grey))
+    data = open(COCO, "rb").read()
+    coef, info = gpu_jpeg.entropy_decode(data)
+    ref = _pil(data)
+    assert (info.height, info.width) == ref.shape[:2]
+    assert np.array_equal(jpeg_ref.reconstruct(coef.numpy(), info), ref)
+
+
+def test_scope_and_errors():
+    arr = _scene(40, 40, 1)
+    with pytest.raises(gpu_jpeg.UnsupportedJpeg):
+        gpu_jpeg.jpeg_info(_jpeg(arr, progressive=True))
+    cmyk = io.BytesIO()
+    Image.fromarray(np.dstack([arr, arr[:, :, :1]]), mode="CMYK").save(cmyk, format="JPEG")
+    with pytest.raises(gpu_jpeg.UnsupportedJpeg):
+        gpu_jpeg.jpeg_info(cmyk.getvalue())
+    good = _jpeg(arr, quality=80)
+    from ovmono3d_amd.lib import OvmError
+    with pytest.raises(OvmError):
+        gpu_jpeg.entropy_decode(good[:len(good) // 2] )               # truncated entropy-coded segment: missing blocks decode from zeros,
+    with pytest.raises(OvmError):                                      # but a cut inside a marker segment is an error
+        gpu_jpeg.jpeg_info(good[:30])
+    with pytest.raises(OvmError):
+        gpu_jpeg.jpeg_info(b"\x89PNG\r\n\x1a\n" + bytes(64))
+    with pytest.raises(RuntimeError):
+        gpu_jpeg.decode_jpeg(good, torch.device("cpu"))                # no CPU fallback of the reconstruction
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,hw,kw", CASES, ids=[c[0] for c in CASES])
+def test_device_decode_equals_pillow(device, name, hw, kw):
+    data = _case_bytes(name, hw, kw)
+    out = gpu_jpeg.decode_jpeg(data, device)
+    assert out.dtype == torch.uint8 and tuple(out.shape) == (hw[0], hw[1], 3)
+    assert np.array_equal(out.cpu().numpy(), _pil(data))
+
+
+@pytest.mark.gpu
+def test_device_decode_coco_example_grey_and_reader(device, tmp_path):
+    data = open(COCO, "rb").read()
+    assert np.array_equal(gpu_jpeg.decode_jpeg(data, device).cpu().numpy(), _pil(data))
+    big = _jpeg(_scene(1080, 1920, 9), quality=85, subsampling=2)
+    assert np.array_equal(gpu_jpeg.decode_jpeg(big, device).cpu().numpy(), _pil(big))
+    grey = _jpeg(_scene(77, 53, 3)[:, :, 0], quality=80)
+    assert np.array_equal(gpu_jpeg.decode_jpeg(grey, device).cpu().numpy(), _pil(grey))
+    # the reader: device decode for baseline files (BGR = cv2.imread order), host reader + upload for the rest
+    from ovmono3d_amd.data.feeding import read_image
+    p1, p2, p3 = str(tmp_path / "a.jpg"), str(tmp_path / "b.jpg"), str(tmp_path / "c.png")
+    open(p1, "wb").write(data)
+    open(p2, "wb").write(_jpeg(_scene(60, 80, 4), progressive=True))
+    Image.fromarray(_scene(31, 47, 5)).save(p3)
+    for p in (p1, p2, p3):
+        for fmt in ("RGB", "BGR"):
+            assert np.array_equal(gpu_jpeg.read_image_device(p, fmt, device).cpu().numpy(), read_image(p, fmt))
