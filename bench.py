@@ -155,7 +155,7 @@ def main():
             out = model(inputs)
         torch.cuda.synchronize()
         if profile:
-            model.engine.profile_enable(True)
+            model.engine.profile_enable(True)      # HIP-event brackets on the launch stream; same-session A/B: they cost nothing (21.4-21.7 ms with all, attention only or none)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -201,7 +201,7 @@ def main():
     tot_ms, launches = prof[dominant]
     avg_ms = tot_ms / max(launches, 1)
     flops_launch = kf[dominant] * B
-    achieved = flops_launch / (avg_ms * 1e-3) / 1e12
+    achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     # HBM-side bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass over this same command
     # (profiles/rNN/pmc_traffic_*.json documents the command and the gfx950 FETCH_SIZE correction; newest round first); null if none matches
     traffic = traffic_source = None

@@ -204,7 +204,7 @@ int ovm_comm_destroy(void* comm);
  * short kernels find free wave slots. Scheduling only: results are unchanged. */
 int ovm_set_corun(OvmHandle* handle, int32_t on);
 
-int ovm_profile_enable(OvmHandle* h, int32_t on);
+int ovm_profile_enable(OvmHandle* h, int32_t on); /* 0 off, 1 every category, else bit (c + 1) selects category c (attn, qkv, proj, fc1, fc2, ln) */
 int ovm_profile_read(OvmHandle* h, float* ms /* [OVM_PROF_NCAT] */, int32_t* launches /* [OVM_PROF_NCAT] */);
 
 /* --- host-side helpers (no GPU needed) -------------------------------------------------------- */

@@ -87,6 +87,7 @@ struct OvmHandle {
   int lastB = 0;
   // optional per-kernel-category timing with HIP events on the caller's stream
   bool prof = false;
+  unsigned prof_mask = ~0u;          // categories that are bracketed while prof is on
   bool corun = false;               // ovm_set_corun
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[OVM_PROF_NCAT];
   size_t prof_used[OVM_PROF_NCAT] = {0};
@@ -309,7 +310,7 @@ int pack_sfp_stage(OvmHandle* h, const WeightMap& wm, const std::string& p1, con
 struct ProfScope {
   OvmHandle* h; int cat; hipStream_t s; hipEvent_t stop = nullptr;
   ProfScope(OvmHandle* h_, int cat_, hipStream_t s_) : h(h_), cat(cat_), s(s_) {
-    if (!h->prof || cat < 0) return;
+    if (!h->prof || cat < 0 || !((h->prof_mask >> cat) & 1u)) return;
     auto& pool = h->prof_ev[cat];
     if (h->prof_used[cat] == pool.size()) {
       hipEvent_t a, b;
@@ -1191,6 +1192,7 @@ int ovm_set_corun(OvmHandle* h, int32_t on) {
 int ovm_profile_enable(OvmHandle* h, int32_t on) {
   if (!h) return OVM_ERR_INVALID;
   h->prof = on != 0;
+  h->prof_mask = (on == 0 || on == 1) ? ~0u : ((unsigned)on >> 1);       // 1 = every category; else bit (c + 1) selects category c
   for (int c = 0; c < OVM_PROF_NCAT; ++c) h->prof_used[c] = 0;
   return OVM_OK;
 }

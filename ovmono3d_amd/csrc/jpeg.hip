@@ -39,6 +39,19 @@ struct Huff {
   // canonical decoding: codes of length l occupy [mincode[l], maxcode[l]]; fast table for codes of <= 9 bits
   int maxcode[18], valptr[17], mincode[17];
   uint16_t fast[512];              // (length << 8) | symbol, 0 = longer than 9 bits
+  int16_t fast_ac[512];            // AC tables: (value << 8) | (run << 4) | (code + magnitude bits) when both fit in the 9-bit window, else 0
+  void build_fast_ac() {
+    for (int i = 0; i < 512; ++i) {
+      fast_ac[i] = 0;
+      const uint16_t f = fast[i];
+      if (!f) continue;
+      const int len = f >> 8, rs = f & 255, run = rs >> 4, mag = rs & 15;
+      if (mag == 0 || len + mag > 9) continue;
+      int k = ((i << len) & 511) >> (9 - mag);                     // the magnitude bits behind the code
+      if (k < (1 << (mag - 1))) k += (int)((~0u) << mag) + 1;      // extend()
+      if (k >= -128 && k <= 127) fast_ac[i] = (int16_t)(k * 256 + run * 16 + len + mag);
+    }
+  }
   bool build() {
     int code = 0, k = 0;
     memset(fast, 0, sizeof(fast));
@@ -66,6 +79,19 @@ struct BitReader {
   uint64_t acc = 0; int n = 0;         // n valid bits at the bottom of acc
   bool hit_marker = false;
   void fill() {
+    if (!hit_marker && p + 8 <= end) {                             // whole bytes at once while no 0xFF is near
+      uint64_t v; memcpy(&v, p, 8);
+      const uint64_t nv = ~v;
+      if (!((nv - 0x0101010101010101ull) & v & 0x8080808080808080ull)) {     // no byte of v is 0xFF
+        const int k = (64 - n) >> 3;
+        if (k > 0) {
+          const uint64_t be = __builtin_bswap64(v);
+          acc = (k == 8) ? be : ((acc << (8 * k)) | (be >> (64 - 8 * k)));
+          p += k; n += 8 * k;
+        }
+        return;
+      }
+    }
     while (n <= 56) {
       uint8_t b = 0;
       if (!hit_marker && p < end) {
@@ -168,6 +194,7 @@ int parse(const uint8_t* d, size_t n, Frame& f, int16_t* coef) {
         if (cnt > 256 || o + 17 + cnt > sl) return OVM_ERR_INVALID;
         memcpy(h.vals, s + o + 17, cnt);
         if (!h.build()) return OVM_ERR_INVALID;
+        if (tc) h.build_fast_ac();
         h.present = true;
         o += 17 + cnt;
       }
@@ -241,6 +268,14 @@ int parse(const uint8_t* d, size_t n, Frame& f, int16_t* coef) {
                 if (sym) dcpred[c] += extend(br.get(sym), sym);
                 blk[0] = (int16_t)dcpred[c];
                 for (int k = 1; k < 64;) {
+                  const int fa = ha.fast_ac[br.peek(9)];
+                  if (fa) {                                            // code and magnitude in one lookup
+                    k += (fa >> 4) & 15;
+                    if (k > 63) return OVM_ERR_INVALID;
+                    br.skip(fa & 15);
+                    blk[kZigzag[k++]] = (int16_t)(fa >> 8);
+                    continue;
+                  }
                   sym = decode_symbol(br, ha);
                   if (sym < 0) return OVM_ERR_INVALID;
                   const int r = sym >> 4, sz = sym & 15;

@@ -296,9 +296,15 @@ class Engine:
             check(self._lib.ovm_set_corun(self._h, int(on)), self._h, "ovm_set_corun")
             self._corun = bool(on)
 
-    def profile_enable(self, on: bool = True) -> None:
+    def profile_enable(self, on: bool = True, only=None) -> None:
+        """HIP-event brackets around the ViT's kernels on the launch stream; ``only`` = category names to bracket (default: all)."""
         self._require()
-        check(self._lib.ovm_profile_enable(self._h, int(on)), self._h, "ovm_profile_enable")
+        v = int(bool(on))
+        if on and only is not None:
+            v = 0
+            for n in only:
+                v |= 2 << _lib.PROF_NAMES.index(n)
+        check(self._lib.ovm_profile_enable(self._h, v), self._h, "ovm_profile_enable")
 
     def profile_read(self) -> Dict[str, Tuple[float, int]]:
         """{category: (total ms, launches)} since profile_enable(True); synchronises the device."""
