@@ -18,6 +18,7 @@ timeout -k 10 200 $B --tower midas --model DPT_Large --canvas 1024 --net-res 608
 timeout -k 10 200 $B --tower sam --model vit_b --canvas 1024 --net-res 608 --proposals oracle2d --no-alt --no-cpu-baseline > $O/bench_sam_b1.json 2> $O/bench_sam_b1.err; echo "sam rc=$?"
 timeout -k 10 300 $B --tower clip --model ViT-B-16 --canvas 1024 --net-res 608 --proposals oracle2d --batch 32 --steps 5 --warmup 2 --no-alt > $O/bench_clip_b32.json 2> $O/bench_clip_b32.err; echo "clip b32 rc=$?"
 timeout -k 10 300 $B --canvas 1036 --net-res 1024 --batch 64 --proposals oracle2d --no-alt --no-cpu-baseline --steps 3 --warmup 1 > $O/bench_c5_b64.json 2> $O/bench_c5_b64.err; echo "c5 rc=$?"
+timeout -k 10 200 python3 $R/scratch/bench_jpeg.py > $O/bench_jpeg.json 2> $O/bench_jpeg.err; echo "jpeg rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $B --steps 10 --warmup 3 --no-cpu-baseline --no-alt > $O/bench_under_rocprof.json 2> $O/kt.err; echo "kernel-trace rc=$?"
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE \
   --output-format csv -d $O/pmc_sq -o sq -- $B --steps 3 --warmup 2 --no-cpu-baseline --no-alt > $O/pmc_sq.json 2> $O/pmc_sq.err; echo "pmc sq rc=$?"
