@@ -12,6 +12,8 @@ for src, dst in (("bench_final.json", "bench_r02_final.json"), ("bench_oracle2d.
     if not os.path.exists(os.path.join(O, src)):
         continue
     json.dump(last(src), open(os.path.join(P, dst), "w"), indent=1)
+if os.path.exists(os.path.join(O, "bench_jpeg.json")):
+    shutil.copy(os.path.join(O, "bench_jpeg.json"), os.path.join(P, "bench_r02_jpeg.jsonl"))
 # kernel statistics: top 60 rows
 rows = open(os.path.join(O, "kernel_stats.csv")).read().splitlines()
 open(os.path.join(P, "kernel_stats_f16x3_vitl14_gdino_T4097_b1.csv"), "w").write("\n".join(rows[:61]) + "\n")
