@@ -22,6 +22,8 @@ for name, hw, kw in [("coco_480x640_420", (480, 640), dict(quality=90, subsampli
         with Image.open(io.BytesIO(data)) as im:
             ref = np.asarray(im.convert("RGB"))
     t_pil = (time.perf_counter() - t0) / n
+    for _ in range(3):
+        coef, info = gpu_jpeg.entropy_decode(data, pin=True)      # first call: pinned allocation
     t0 = time.perf_counter()
     for _ in range(n):
         coef, info = gpu_jpeg.entropy_decode(data, pin=True)
