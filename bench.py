@@ -151,6 +151,12 @@ def main():
             d["image"] = d["image"].to(dev)
             inputs.append(d)
         ndet = 0
+        c_time = [0.0]
+        if os.environ.get("OVM_BENCH_HOSTTIME") == "1" and use_gdino:      # diagnostic: seconds inside the one C call vs the whole step
+            _inner = model.engine.infer_gdino
+            def _timed(*a, **k):
+                t = time.perf_counter(); r = _inner(*a, **k); c_time[0] += time.perf_counter() - t; return r
+            model.engine.infer_gdino = _timed
         for _ in range(warmup):
             out = model(inputs)
         torch.cuda.synchronize()
@@ -159,6 +165,7 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        c_time[0] = 0.0
         t0 = time.perf_counter()
         for _ in range(steps):
             out = model(inputs)
@@ -167,6 +174,8 @@ def main():
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
+        if os.environ.get("OVM_BENCH_HOSTTIME") == "1" and use_gdino and profile:
+            print(f"[hosttime] step {dt / steps * 1e3:.3f} ms, inside ovm_infer {c_time[0] / steps * 1e3:.3f} ms", file=sys.stderr)
         prof = model.engine.profile_read() if profile else None
         if profile:
             model.engine.profile_enable(False)

@@ -132,8 +132,8 @@ class RCNN3D:
             raise ValueError("category names must be lower-case / stripped for ROIHeads3DGDINO (reference roi_heads_gdino.py:162: "
                              "filtered_texts.index([class_name]) raises for names that build_caption normalised)")
         if remap != list(range(len(cap_list))) and n > 0:
-            cls = rec[:, 5].contiguous().view(torch.int32)
-            rec[:, 5] = torch.tensor(remap, dtype=torch.int32, device=rec.device)[cls.long()].view(torch.float32)
+            cls = rec.view(torch.int32)[:, 5]                      # rec: row-contiguous block of records
+            cls.copy_(torch.tensor(remap, dtype=torch.int32, device=rec.device)[cls.long()])
         size = (int(images.native[0].orig_height), int(images.native[0].orig_width))
         if n == 0:
             from ...structures import Boxes, Instances
