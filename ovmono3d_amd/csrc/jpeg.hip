@@ -26,292 +26,9 @@
 #include <cstring>
 
 #include "../../include/ovm3d.h"
+#include "jpeg_host.hpp"
 
 namespace {
-
-const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
-                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-
-struct Huff {
-  bool present = false;
-  uint8_t bits[17] = {0}, vals[256] = {0};
-  // canonical decoding: codes of length l occupy [mincode[l], maxcode[l]]; fast table for codes of <= 9 bits
-  int maxcode[18], valptr[17], mincode[17];
-  uint16_t fast[512];              // (length << 8) | symbol, 0 = longer than 9 bits
-  int16_t fast_ac[512];            // AC tables: (value << 8) | (run << 4) | (code + magnitude bits) when both fit in the 9-bit window, else 0
-  void build_fast_ac() {
-    for (int i = 0; i < 512; ++i) {
-      fast_ac[i] = 0;
-      const uint16_t f = fast[i];
-      if (!f) continue;
-      const int len = f >> 8, rs = f & 255, run = rs >> 4, mag = rs & 15;
-      if (mag == 0 || len + mag > 9) continue;
-      int k = ((i << len) & 511) >> (9 - mag);                     // the magnitude bits behind the code
-      if (k < (1 << (mag - 1))) k += (int)((~0u) << mag) + 1;      // extend()
-      if (k >= -128 && k <= 127) fast_ac[i] = (int16_t)(k * 256 + run * 16 + len + mag);
-    }
-  }
-  bool build() {
-    int code = 0, k = 0;
-    memset(fast, 0, sizeof(fast));
-    for (int l = 1; l <= 16; ++l) {
-      valptr[l] = k; mincode[l] = code;
-      for (int i = 0; i < bits[l]; ++i, ++k, ++code) {
-        if (k >= 256) return false;
-        if (l <= 9) {
-          const int lo = code << (9 - l), n = 1 << (9 - l);
-          if (lo + n > 512) return false;
-          for (int j = 0; j < n; ++j) fast[lo + j] = (uint16_t)((l << 8) | vals[k]);
-        }
-      }
-      maxcode[l] = bits[l] ? code - 1 : -1;
-      if (code > (1 << l)) return false;
-      code <<= 1;
-    }
-    maxcode[17] = 0x7fffffff;
-    return true;
-  }
-};
-
-struct BitReader {
-  const uint8_t* p; const uint8_t* end;
-  uint64_t acc = 0; int n = 0;         // n valid bits at the bottom of acc
-  bool hit_marker = false;
-  void fill() {
-    if (!hit_marker && p + 8 <= end) {                             // whole bytes at once while no 0xFF is near
-      uint64_t v; memcpy(&v, p, 8);
-      const uint64_t nv = ~v;
-      if (!((nv - 0x0101010101010101ull) & v & 0x8080808080808080ull)) {     // no byte of v is 0xFF
-        const int k = (64 - n) >> 3;
-        if (k > 0) {
-          const uint64_t be = __builtin_bswap64(v);
-          acc = (k == 8) ? be : ((acc << (8 * k)) | (be >> (64 - 8 * k)));
-          p += k; n += 8 * k;
-        }
-        return;
-      }
-    }
-    while (n <= 56) {
-      uint8_t b = 0;
-      if (!hit_marker && p < end) {
-        b = *p;
-        if (b == 0xFF) {
-          if (p + 1 < end && p[1] == 0x00) p += 2;            // stuffed byte
-          else { hit_marker = true; b = 0; }                   // a marker ends the segment: zeros from here on (as libjpeg)
-        } else ++p;
-      } else hit_marker = hit_marker || p >= end;
-      acc = (acc << 8) | b; n += 8;
-    }
-  }
-  inline int peek(int k) { if (n < k) fill(); return (int)((acc >> (n - k)) & ((1u << k) - 1)); }
-  inline void skip(int k) { n -= k; }
-  inline int get(int k) { const int v = peek(k); n -= k; return v; }
-  void reset() { acc = 0; n = 0; }
-};
-
-inline int decode_symbol(BitReader& br, const Huff& h) {
-  const int look = br.peek(9);
-  const uint16_t f = h.fast[look];
-  if (f) { br.skip(f >> 8); return f & 255; }
-  int code = br.peek(16), l;
-  for (l = 10; l <= 16; ++l)
-    if ((code >> (16 - l)) <= h.maxcode[l] && h.bits[l]) break;
-  if (l > 16) return -1;
-  const int c = code >> (16 - l);
-  if (c < h.mincode[l]) return -1;
-  br.skip(l);
-  return h.vals[h.valptr[l] + c - h.mincode[l]];
-}
-
-inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
-
-struct Frame {
-  OvmJpegInfo info;
-  int cid[3] = {0, 0, 0};
-  size_t plane_off[3] = {0, 0, 0};      // in blocks
-  int restart = 0;
-  Huff dc[4], ac[4];
-  bool have_sof = false, jfif = false, adobe = false; int adobe_transform = -1;
-};
-
-inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
-
-// walks the marker segments up to (not into) the first SOS when `scan_cb` is null, else decodes every scan
-int parse(const uint8_t* d, size_t n, Frame& f, int16_t* coef) {
-  if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return OVM_ERR_INVALID;
-  memset(&f.info, 0, sizeof(f.info));
-  size_t pos = 2;
-  int dcpred[3];
-  while (pos + 4 <= n) {
-    if (d[pos] != 0xFF) return OVM_ERR_INVALID;
-    while (pos < n && d[pos] == 0xFF) ++pos;              // fill bytes
-    if (pos >= n) return OVM_ERR_INVALID;
-    const int m = d[pos++];
-    if (m == 0xD9) break;                                 // EOI
-    if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;  // standalone
-    if (pos + 2 > n) return OVM_ERR_INVALID;
-    const int len = be16(d + pos);
-    if (len < 2 || pos + len > n) return OVM_ERR_INVALID;
-    const uint8_t* s = d + pos + 2; const int sl = len - 2;
-    if (m == 0xC0 || m == 0xC1) {
-      if (f.have_sof || sl < 6) return OVM_ERR_INVALID;
-      if (s[0] != 8) return OVM_ERR_UNSUPPORTED;
-      OvmJpegInfo& I = f.info;
-      I.height = be16(s + 1); I.width = be16(s + 3); I.ncomp = s[5];
-      if (I.height <= 0 || I.width <= 0) return OVM_ERR_UNSUPPORTED;      // (height 0 = DNL-defined: not handled)
-      if (I.ncomp != 1 && I.ncomp != 3) return OVM_ERR_UNSUPPORTED;
-      if (sl < 6 + 3 * I.ncomp) return OVM_ERR_INVALID;
-      for (int c = 0; c < I.ncomp; ++c) {
-        f.cid[c] = s[6 + 3 * c]; I.h[c] = s[7 + 3 * c] >> 4; I.v[c] = s[7 + 3 * c] & 15; I.qidx[c] = s[8 + 3 * c];
-        if (I.h[c] < 1 || I.h[c] > 4 || I.v[c] < 1 || I.v[c] > 4 || I.qidx[c] > 3) return OVM_ERR_INVALID;
-      }
-      if (I.ncomp == 1) { I.h[0] = I.v[0] = 1; }          // a single component is never subsampled (libjpeg: MCU = one block)
-      else {
-        if (I.h[1] != 1 || I.v[1] != 1 || I.h[2] != 1 || I.v[2] != 1 || I.h[0] > 2 || I.v[0] > 2) return OVM_ERR_UNSUPPORTED;
-        if (I.h[0] == 1 && I.v[0] == 2) return OVM_ERR_UNSUPPORTED;       // 4:4:0 (h1v2): Pillow cannot write it, so it could not be pinned
-      }
-      I.hmax = I.h[0]; I.vmax = I.v[0];
-      const int mcux = (I.width + 8 * I.hmax - 1) / (8 * I.hmax), mcuy = (I.height + 8 * I.vmax - 1) / (8 * I.vmax);
-      size_t off = 0;
-      for (int c = 0; c < I.ncomp; ++c) {
-        I.bw[c] = mcux * I.h[c]; I.bh[c] = mcuy * I.v[c];
-        I.cw[c] = (I.width * I.h[c] + I.hmax - 1) / I.hmax; I.ch[c] = (I.height * I.v[c] + I.vmax - 1) / I.vmax;
-        f.plane_off[c] = off; off += (size_t)I.bw[c] * I.bh[c];
-      }
-      if (off > (size_t)0x7fffffff / 64) return OVM_ERR_UNSUPPORTED;
-      I.coef_blocks = (int32_t)off;
-      f.have_sof = true;
-    } else if (m == 0xC4) {
-      int o = 0;
-      while (o + 17 <= sl) {
-        const int tc = s[o] >> 4, th = s[o] & 15;
-        if (tc > 1 || th > 3) return OVM_ERR_INVALID;
-        Huff& h = tc ? f.ac[th] : f.dc[th];
-        int cnt = 0;
-        h.bits[0] = 0;
-        for (int l = 1; l <= 16; ++l) { h.bits[l] = s[o + l]; cnt += h.bits[l]; }
-        if (cnt > 256 || o + 17 + cnt > sl) return OVM_ERR_INVALID;
-        memcpy(h.vals, s + o + 17, cnt);
-        if (!h.build()) return OVM_ERR_INVALID;
-        if (tc) h.build_fast_ac();
-        h.present = true;
-        o += 17 + cnt;
-      }
-    } else if (m == 0xDB) {
-      int o = 0;
-      while (o < sl) {
-        const int pq = s[o] >> 4, tq = s[o] & 15;
-        if (tq > 3 || pq > 1 || o + 1 + 64 * (pq + 1) > sl) return OVM_ERR_INVALID;
-        for (int i = 0; i < 64; ++i) f.info.qt[tq][kZigzag[i]] = pq ? (uint16_t)be16(s + o + 1 + 2 * i) : s[o + 1 + i];
-        o += 1 + 64 * (pq + 1);
-      }
-    } else if (m == 0xDD) {
-      if (sl < 2) return OVM_ERR_INVALID;
-      f.restart = be16(s);
-    } else if (m == 0xE0) {
-      if (sl >= 5 && !memcmp(s, "JFIF", 5)) f.jfif = true;
-    } else if (m == 0xEE) {
-      if (sl >= 12 && !memcmp(s, "Adobe", 5)) { f.adobe = true; f.adobe_transform = s[11]; }
-    } else if (m == 0xC2 || m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
-      return OVM_ERR_UNSUPPORTED;                          // progressive, lossless, differential, arithmetic
-    } else if (m == 0xCC) {
-      return OVM_ERR_UNSUPPORTED;                          // arithmetic conditioning
-    } else if (m == 0xDA) {
-      if (!f.have_sof) return OVM_ERR_INVALID;
-      if (!coef) break;                                    // header walk ends here
-      const OvmJpegInfo& I = f.info;
-      if (sl < 1) return OVM_ERR_INVALID;
-      const int ns = s[0];
-      if (ns < 1 || ns > I.ncomp || sl < 1 + 2 * ns + 3) return OVM_ERR_INVALID;
-      int sc[3], td[3], ta[3];
-      for (int i = 0; i < ns; ++i) {
-        int c = -1;
-        for (int q = 0; q < I.ncomp; ++q) if (f.cid[q] == s[1 + 2 * i]) c = q;
-        if (c < 0) return OVM_ERR_INVALID;
-        sc[i] = c; td[i] = s[2 + 2 * i] >> 4; ta[i] = s[2 + 2 * i] & 15;
-        if (td[i] > 3 || ta[i] > 3 || !f.dc[td[i]].present || !f.ac[ta[i]].present) return OVM_ERR_INVALID;
-      }
-      if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63 || s[3 + 2 * ns] != 0) return OVM_ERR_UNSUPPORTED;   // spectral selection = progressive
-      BitReader br; br.p = d + pos + len; br.end = d + n;
-      int mx, my;                                          // MCU grid of this scan
-      if (ns == 1) { mx = (I.cw[sc[0]] + 7) / 8; my = (I.ch[sc[0]] + 7) / 8; }
-      else { mx = I.bw[0] / I.h[0]; my = I.bh[0] / I.v[0]; }
-      dcpred[0] = dcpred[1] = dcpred[2] = 0;
-      int until_restart = f.restart ? f.restart : -1, next_rst = 0;
-      for (int yy = 0; yy < my; ++yy)
-        for (int xx = 0; xx < mx; ++xx) {
-          if (until_restart == 0) {
-            // byte-align, expect RSTn
-            br.reset();
-            const uint8_t* q = br.p;
-            while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) {
-              if (q[0] == 0xFF && q[1] != 0x00 && q[1] != 0xFF) break;
-              ++q;
-            }
-            if (q + 1 >= br.end || !(q[0] == 0xFF && q[1] == 0xD0 + next_rst)) return OVM_ERR_INVALID;
-            br.p = q + 2; br.hit_marker = false;
-            next_rst = (next_rst + 1) & 7;
-            dcpred[0] = dcpred[1] = dcpred[2] = 0;
-            until_restart = f.restart;
-          }
-          for (int i = 0; i < ns; ++i) {
-            const int c = sc[i];
-            const int nh = ns == 1 ? 1 : I.h[c], nv = ns == 1 ? 1 : I.v[c];
-            const Huff& hd = f.dc[td[i]]; const Huff& ha = f.ac[ta[i]];
-            for (int v = 0; v < nv; ++v)
-              for (int h = 0; h < nh; ++h) {
-                const int by = yy * nv + v, bx = xx * nh + h;
-                int16_t* blk = coef + (f.plane_off[c] + (size_t)by * I.bw[c] + bx) * 64;
-                int sym = decode_symbol(br, hd);
-                if (sym < 0 || sym > 11) return OVM_ERR_INVALID;
-                if (sym) dcpred[c] += extend(br.get(sym), sym);
-                blk[0] = (int16_t)dcpred[c];
-                for (int k = 1; k < 64;) {
-                  const int fa = ha.fast_ac[br.peek(9)];
-                  if (fa) {                                            // code and magnitude in one lookup
-                    k += (fa >> 4) & 15;
-                    if (k > 63) return OVM_ERR_INVALID;
-                    br.skip(fa & 15);
-                    blk[kZigzag[k++]] = (int16_t)(fa >> 8);
-                    continue;
-                  }
-                  sym = decode_symbol(br, ha);
-                  if (sym < 0) return OVM_ERR_INVALID;
-                  const int r = sym >> 4, sz = sym & 15;
-                  if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
-                  k += r;
-                  if (k > 63) return OVM_ERR_INVALID;
-                  blk[kZigzag[k]] = (int16_t)extend(br.get(sz), sz);
-                  ++k;
-                }
-              }
-          }
-          if (until_restart > 0) --until_restart;
-        }
-      // resume the marker walk behind the entropy-coded segment
-      const uint8_t* q = br.p;
-      if (!br.hit_marker) {
-        while (q + 1 < br.end && !(q[0] == 0xFF && q[1] != 0x00 && q[1] != 0xFF && !(q[1] >= 0xD0 && q[1] <= 0xD7))) ++q;
-      }
-      pos = (size_t)(q - d);
-      continue;
-    }
-    pos += len;
-  }
-  if (!f.have_sof) return OVM_ERR_INVALID;
-  OvmJpegInfo& I = f.info;
-  if (I.ncomp == 1) I.colorspace = 0;
-  else if (f.jfif) I.colorspace = 1;
-  else if (f.adobe) I.colorspace = f.adobe_transform == 0 ? 2 : 1;
-  else I.colorspace = (f.cid[0] == 'R' && f.cid[1] == 'G' && f.cid[2] == 'B') ? 2 : 1;
-  for (int c = 0; c < I.ncomp; ++c) {
-    bool any = false;
-    for (int i = 0; i < 64; ++i) any = any || I.qt[I.qidx[c]][i] != 0;
-    if (!any) return OVM_ERR_INVALID;                      // quantisation table never defined
-  }
-  return OVM_OK;
-}
 
 // ------------------------------------------------------------------------------------------------
 // device side
@@ -455,27 +172,10 @@ __global__ void jpeg_color_kernel(const uint8_t* __restrict__ planes, JpegDev J,
 
 extern "C" {
 
-int ovm_host_jpeg_info(const uint8_t* data, size_t n, OvmJpegInfo* info) {
-  if (!data || !info) return OVM_ERR_INVALID;
-  Frame f;
-  const int r = parse(data, n, f, nullptr);
-  if (r) return r;
-  *info = f.info;
-  return OVM_OK;
-}
+int ovm_host_jpeg_info(const uint8_t* data, size_t n, OvmJpegInfo* info) { return ovm_jpeg::host_info(data, n, info); }
 
 int ovm_host_jpeg_entropy_decode(const uint8_t* data, size_t n, int16_t* coef, int64_t coef_capacity, OvmJpegInfo* info) {
-  if (!data || !coef || !info) return OVM_ERR_INVALID;
-  Frame f;
-  int r = parse(data, n, f, nullptr);
-  if (r) return r;
-  if (coef_capacity < (int64_t)f.info.coef_blocks * 64) return OVM_ERR_CAPACITY;
-  memset(coef, 0, sizeof(int16_t) * 64 * (size_t)f.info.coef_blocks);
-  Frame g;
-  r = parse(data, n, g, coef);
-  if (r) return r;
-  *info = g.info;
-  return OVM_OK;
+  return ovm_jpeg::host_entropy_decode(data, n, coef, coef_capacity, info);
 }
 
 int ovm_jpeg_reconstruct(const int16_t* coef, const OvmJpegInfo* info, uint8_t* planes, uint8_t* rgb, ovm_stream_t stream) {

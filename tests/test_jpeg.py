@@ -101,6 +101,46 @@ def test_scope_and_errors():
         gpu_jpeg.decode_jpeg(good, torch.device("cpu"))                # no CPU fallback of the reconstruction
 
 
+def test_corrupt_streams_are_refused_or_decoded_never_worse():
+    """The host half parses untrusted files: byte flips, truncations and spliced garbage must end in an error code or in a
+    decode of the declared size - never in a crash or an out-of-range write (the coefficient buffer is guarded by canaries)."""
+    import ctypes as C
+    from ovmono3d_amd import lib as _lib
+    L = _lib.load()
+    rng = np.random.default_rng(0)
+    seeds = [_jpeg(_scene(40, 56, 2), quality=80, subsampling=2), _jpeg(_scene(33, 20, 3), quality=60, subsampling=0, restart_marker_blocks=2),
+             _jpeg(_scene(24, 24, 4)[:, :, 0], quality=70, optimize=True), open(COCO, "rb").read()[:6000]]
+    outcomes = {0: 0}
+    for it in range(400):
+        data = bytearray(seeds[it % len(seeds)])
+        kind = it % 4
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                data[int(rng.integers(2, len(data)))] = int(rng.integers(0, 256))
+        elif kind == 1:
+            data = data[:int(rng.integers(2, len(data)))]
+        elif kind == 2:
+            i = int(rng.integers(2, len(data)))
+            data[i:i] = bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))
+        else:
+            i = int(rng.integers(2, len(data) - 8))
+            del data[i:i + int(rng.integers(1, 8))]
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data))
+        info = _lib.OvmJpegInfo()
+        rc = L.ovm_host_jpeg_info(C.addressof(buf), len(data), C.byref(info))
+        outcomes[rc] = outcomes.get(rc, 0) + 1
+        if rc != 0:
+            assert rc in (-1, -6), rc
+            continue
+        assert 0 < info.coef_blocks <= (1 << 22) and info.ncomp in (1, 3)
+        nb = int(info.coef_blocks)
+        coef = np.full((nb + 2) * 64, 0x5a5a, dtype=np.int16)
+        rc = L.ovm_host_jpeg_entropy_decode(C.addressof(buf), len(data), coef[64:].ctypes.data, nb * 64, C.byref(info))
+        assert rc in (0, -1, -6), rc
+        assert (coef[:64] == 0x5a5a).all() and (coef[-64:] == 0x5a5a).all(), "wrote outside the coefficient planes"
+    assert outcomes.get(-1, 0) > 20, outcomes                   # the mutations did reach the parser's error paths
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,hw,kw", CASES, ids=[c[0] for c in CASES])
 def test_device_decode_equals_pillow(device, name, hw, kw):
