@@ -79,6 +79,13 @@ def main():
             dist.init_process_group(backend)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    if world > 1:
+        # N ranks build their synthetic checkpoints on the host at the same time: share the cores instead of oversubscribing them N-fold
+        try:
+            avail_cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail_cores = os.cpu_count() or 1
+        torch.set_num_threads(max(1, avail_cores // world))
 
     from common import build_cfg, build_clip_cfg, build_mae_cfg, build_midas_cfg, build_sam_cfg, oracle_params
     # experiment knobs of libovm3d (ovm_tune_set), e.g. OVM_TUNE=gdino_branches=0 - never set by the driver's runs
