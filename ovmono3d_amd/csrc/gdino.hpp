@@ -37,6 +37,7 @@ struct AttnF32Params {
   // rel_gh x rel_gw grid (key = kh * rel_gw + kw) and score(q, key) += rel_h[q][kh] + rel_w[q][kw]; both tables depend on the
   // query's content and are laid out [b1][q][b2][ldrel] (launch_relpos_tables writes them). null: none
   const float* rel_h; const float* rel_w; int rel_gw; int ldrel;
+  int bias_vec;                                   // set by launch_attn_f32
 };
 int launch_attn_f32(const AttnF32Params& p, hipStream_t s);
 

@@ -134,10 +134,14 @@ constexpr int kKC = 144;                       // keys per LDS chunk (= one Swin
 
 template <int DH>
 __global__ __launch_bounds__(576) void attn_f32_kernel(const AttnF32Params p) {
-  constexpr int LDK = DH + 2, LDV = DH + 4, NS = DH / 4, ND = DH / 16, NKT = kKC / 16;
+  // LDS: K rows [kKC][DH + 4] and V TRANSPOSED [DH][kKC + 4], so that both MFMA A operands are 16-byte fragment reads: a lane's
+  // slice of the head dimension is contiguous (k = g * NS + s, the same regrouping on the Q side), and the 4 keys a lane feeds to
+  // the 4 PV MFMAs of a key tile are contiguous in the transposed V. Row strides 36 / 68 / 20 and 148 floats keep the 16 lanes
+  // of a read phase on distinct banks.
+  constexpr int LDK = DH + 4, LDT = kKC + 4, NS = DH / 4, ND = DH / 16, NKT = kKC / 16;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* Ks = (float*)smem_raw;                // [kKC][LDK]
-  float* Vs = Ks + kKC * LDK;                  // [kKC][LDV]   (kKC * LDK * 4 is a multiple of 16)
+  float* Vt = Ks + kKC * LDK;                  // [DH][LDT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
   const int li = lane & 15, g = lane >> 4;
   const int z = blockIdx.y, b1 = z / p.nb2, b2 = z - b1 * p.nb2;
@@ -151,9 +155,9 @@ __global__ __launch_bounds__(576) void attn_f32_kernel(const AttnF32Params p) {
   float qf[NS];
   {
     const float sc = p.scale * kLog2e;
-    const float* qr = qb + (size_t)qi * p.ldq;
+    const float* qr = qb + (size_t)qi * p.ldq + g * NS;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) qf[s] = qr[4 * s + g] * sc;
+    for (int s = 0; s < NS; ++s) qf[s] = qr[s] * sc;
   }
   const float* bh = p.bias_h ? p.bias_h + (size_t)b2 * p.sbh + (size_t)qi * p.ldbh : nullptr;
   const float* bb = p.bias_b ? p.bias_b + (size_t)b1 * p.sbb + (size_t)qi * p.ldbb : nullptr;
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(576) void attn_f32_kernel(const AttnF32Params p) {
 
   for (int kc = 0; kc < p.Tk; kc += kKC) {
     __syncthreads();
-    // stage K / V rows kc .. kc+kKC (zero beyond Tk): DH/4 float4 pieces per row
+    // stage K / V rows kc .. kc+kKC (zero beyond Tk): DH/4 float4 pieces per row; V goes in transposed
     for (int t = tid; t < kKC * (DH / 4); t += nthr) {
       const int r = t / (DH / 4), c = (t - r * (DH / 4)) * 4;
       f32x4 kv = (f32x4){0.f, 0.f, 0.f, 0.f}, vv = kv;
@@ -175,9 +179,9 @@ __global__ __launch_bounds__(576) void attn_f32_kernel(const AttnF32Params p) {
         kv = *(const f32x4*)(kb + (size_t)(kc + r) * p.ldk + c);
         vv = *(const f32x4*)(vb + (size_t)(kc + r) * p.ldv + c);
       }
-      float* kd = Ks + r * LDK + c;
-      kd[0] = kv[0]; kd[1] = kv[1]; kd[2] = kv[2]; kd[3] = kv[3];
-      *(f32x4*)(Vs + r * LDV + c) = vv;
+      *(f32x4*)(Ks + r * LDK + c) = kv;
+      float* vd = Vt + c * LDT + r;
+      vd[0] = vv[0]; vd[LDT] = vv[1]; vd[2 * LDT] = vv[2]; vd[3 * LDT] = vv[3];
     }
     __syncthreads();
     if (!wave_active) continue;
@@ -189,22 +193,37 @@ __global__ __launch_bounds__(576) void attn_f32_kernel(const AttnF32Params p) {
     for (int kt = 0; kt < NKT; ++kt) {
       if (kt < nkt) {                          // wave-uniform
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* kr = Ks + (kt * 16 + li) * LDK + g;
+        const float* kr = Ks + (kt * 16 + li) * LDK + g * NS;
+        f32x4 kq[NS / 4];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[4 * s], qf[s], acc, 0, 0, 0);
+        for (int j = 0; j < NS / 4; ++j) kq[j] = *(const f32x4*)(kr + 4 * j);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kc + kt * 16 + g * 4 + r;
-          float x = acc[r];
-          if (key < p.Tk) {
-            if (bh) x += bh[key] * kLog2e;
-            if (bb) x += bb[key] * kLog2e;
-            if (rh) { const int kh = key / p.rel_gw; x += (rh[kh] + rw[key - kh * p.rel_gw]) * kLog2e; }
+        for (int s = 0; s < NS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kq[s >> 2][s & 3], qf[s], acc, 0, 0, 0);
+        const int key0 = kc + kt * 16 + g * 4;
+        if (p.bias_vec) {                      // wave-uniform: Tk % 4 == 0 and 16-byte aligned bias rows -> 4 keys per load
+          if (key0 < p.Tk) {
+            if (bh) { const f32x4 b = *(const f32x4*)(bh + key0); acc[0] += b[0] * kLog2e; acc[1] += b[1] * kLog2e; acc[2] += b[2] * kLog2e; acc[3] += b[3] * kLog2e; }
+            if (bb) { const f32x4 b = *(const f32x4*)(bb + key0); acc[0] += b[0] * kLog2e; acc[1] += b[1] * kLog2e; acc[2] += b[2] * kLog2e; acc[3] += b[3] * kLog2e; }
           } else {
-            x = -INFINITY;
+            acc = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
           }
-          acc[r] = x;
-          cmax = fmaxf(cmax, x);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, acc[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = key0 + r;
+            float x = acc[r];
+            if (key < p.Tk) {
+              if (bh) x += bh[key] * kLog2e;
+              if (bb) x += bb[key] * kLog2e;
+              if (rh) { const int kh = key / p.rel_gw; x += (rh[kh] + rw[key - kh * p.rel_gw]) * kLog2e; }
+            } else {
+              x = -INFINITY;
+            }
+            acc[r] = x;
+            cmax = fmaxf(cmax, x);
+          }
         }
         st[kt] = acc;
       } else {
@@ -227,10 +246,10 @@ __global__ __launch_bounds__(576) void attn_f32_kernel(const AttnF32Params p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { pr[r] = exp2f(st[kt][r] - msafe); l += pr[r]; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float* vr = Vs + (kt * 16 + g * 4 + r) * LDV + li;
+        for (int d = 0; d < ND; ++d) {
+          const f32x4 vv = *(const f32x4*)(Vt + (d * 16 + li) * LDT + kt * 16 + g * 4);
 #pragma unroll
-          for (int d = 0; d < ND; ++d) o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[d * 16], pr[r], o[d], 0, 0, 0);
+          for (int r = 0; r < 4; ++r) o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[r], pr[r], o[d], 0, 0, 0);
         }
       }
     }
@@ -518,12 +537,16 @@ int launch_attn_f32(const AttnF32Params& p, hipStream_t s) {
   const int qb = 16 * nw;
   const dim3 grid((p.Tq + qb - 1) / qb, (unsigned)(p.nb1 * p.nb2)), block(64 * nw);
   if ((long)p.nb1 * p.nb2 > 65535) return OVM_ERR_CAPACITY;
+  AttnF32Params pv = p;                                   // bias rows readable as float4 (4 keys per lane and key tile)?
+  pv.bias_vec = (p.Tk % 4 == 0) && !p.rel_h && (p.bias_h || p.bias_b) &&
+                (!p.bias_h || (al16(p.bias_h) && p.ldbh % 4 == 0 && p.sbh % 4 == 0)) &&
+                (!p.bias_b || (al16(p.bias_b) && p.ldbb % 4 == 0 && p.sbb % 4 == 0));
 #define OVM_ATTN_F32(DH_)                                                                              \
   {                                                                                                    \
-    const int smem = kKC * ((DH_) + 2) * 4 + kKC * ((DH_) + 4) * 4;                                    \
+    const int smem = kKC * ((DH_) + 4) * 4 + (DH_) * (kKC + 4) * 4;                                    \
     static bool set = false;                                                                           \
     if (!set && smem > 65536) { (void)hipFuncSetAttribute((const void*)attn_f32_kernel<DH_>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); set = true; } \
-    hipLaunchKernelGGL((attn_f32_kernel<DH_>), grid, block, smem, s, p);                               \
+    hipLaunchKernelGGL((attn_f32_kernel<DH_>), grid, block, smem, s, pv);                               \
   }
   if (p.DH == 16) OVM_ATTN_F32(16)
   else if (p.DH == 32) OVM_ATTN_F32(32)
