@@ -29,7 +29,7 @@ extern "C" {
 #define OVM_ERR_MISSING_WEIGHT (-3)
 #define OVM_ERR_SHAPE (-4)
 #define OVM_ERR_CAPACITY (-5)
-#define OVM_ERR_UNSUPPORTED (-6) /* a valid input outside the documented scope of the call (e.g. a progressive JPEG) */
+#define OVM_ERR_UNSUPPORTED (-6) /* a valid input outside the documented scope of the call (e.g. a CMYK JPEG) */
 
 #define OVM_REC_FLOATS 48 /* detection record width, see OvmDet3D */
 
@@ -381,8 +381,9 @@ int ovm_resize_bilinear_f32(const float* src, int32_t B, int32_t H, int32_t W, i
  * host into coefficient planes (int16 [coef_blocks][64] in natural order, component after component, each plane bw x bh blocks =
  * whole MCUs); ovm_jpeg_reconstruct dequantises, runs the 8 x 8 inverse DCT, upsamples the chroma and converts the colours on the
  * device into rgb [height][width][3] (planes: device scratch of coef_blocks * 64 bytes). Bit-identical to libjpeg-turbo / Pillow
- * `Image.open(f).convert("RGB")`. Scope: 8-bit baseline / extended-sequential Huffman JPEGs, grey or 3 components with luma
- * sampling 1x1 / 2x1 / 2x2; anything else (progressive, arithmetic, 12-bit, CMYK) -> OVM_ERR_UNSUPPORTED from the two host
+ * `Image.open(f).convert("RGB")`. Scope: 8-bit Huffman JPEGs - baseline, extended-sequential and progressive (every scan of the
+ * progression present) -, grey or 3 components with luma sampling 1x1 / 2x1 / 2x2; anything else (arithmetic coding, 12-bit, CMYK,
+ * 4:4:0, an incomplete progression) -> OVM_ERR_UNSUPPORTED from the two host
  * calls, a corrupt stream -> OVM_ERR_INVALID. */
 typedef struct OvmJpegInfo {
   int32_t width, height, ncomp;   /* ncomp 1 or 3 */

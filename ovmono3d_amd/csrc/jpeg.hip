@@ -3,7 +3,7 @@
 // The reference reads its images with cv2.imread (demo/demo.py:52) / detectron2's read_image = Pillow
 // (cubercnn/data/dataset_mapper.py:38), i.e. with libjpeg-turbo at its defaults: JDCT_ISLOW, fancy upsampling, YCbCr -> RGB through
 // the integer tables of jdcolor.c. A baseline JPEG is (1) a Huffman-coded stream of quantised DCT coefficients - inherently serial,
-// decoded here on the host (`ovm_host_jpeg_entropy_decode`) - and (2) dequantisation, an 8 x 8 inverse DCT per block, chroma
+// decoded here on the host (`ovm_host_jpeg_entropy_decode`, jpeg_host.hpp; progressive files add their scans' bands and bit planes to the same coefficient planes) - and (2) dequantisation, an 8 x 8 inverse DCT per block, chroma
 // upsampling and a colour transform per pixel - data parallel, all integer arithmetic, done here on the device
 // (`ovm_jpeg_reconstruct`) so that the image is born in HBM as the [H][W][3] uint8 tensor the resize kernel (resize.hip) and the
 // patch gather consume; what crosses PCIe is the coefficient planes (int16, mostly zero).
@@ -17,8 +17,9 @@
 //   jdcolor.c   build_ycc_rgb_table / ycc_rgb_convert - R = Y + (91881 Cr' + 2^15 >> 16), B = Y + (116130 Cb' + 2^15 >> 16),
 //               G = Y + ((-22554 Cb' - 46802 Cr' + 2^15) >> 16), Cb' = Cb - 128, clamped to 0..255
 //   jdapimin.c  default_decompress_parms - colour space from the JFIF / Adobe markers or the component ids
-// Scope: 8-bit baseline / extended-sequential Huffman streams (SOF0 / SOF1), 1 component or 3 components with chroma at 1 x 1 and
-// luma at 1x1, 2x1 or 2x2, interleaved or one scan per component, restart intervals. Progressive, arithmetic-coded, 12-bit,
+// Scope: 8-bit Huffman streams - baseline, extended-sequential and progressive (SOF0 / SOF1 / SOF2; a progression must be complete:
+// libjpeg smooths an incomplete one across blocks, which is not reproduced) -, 1 component or 3 components with chroma at 1 x 1 and
+// luma at 1x1, 2x1 or 2x2, interleaved or one scan per component, restart intervals. Arithmetic-coded, 12-bit,
 // 4-component and odd sampling layouts return OVM_ERR_UNSUPPORTED from ovm_host_jpeg_info (the caller's other decoder handles them,
 // as it handles PNG); a truncated or corrupt stream returns OVM_ERR_INVALID.
 #include <hip/hip_runtime.h>

@@ -105,6 +105,80 @@ inline int decode_symbol(BitReader& br, const Huff& h) {
 
 inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
 
+// ---- progressive mode (SOF2; ITU T.81 Annex G as libjpeg's jdphuff.c implements it): every scan adds a band of coefficients
+// (spectral selection Ss..Se) at a bit position (successive approximation Ah -> Al) to the same coefficient planes ----
+inline int prog_dc_first(BitReader& br, const Huff& hd, int16_t* blk, int& pred, int Al) {
+  const int sym = decode_symbol(br, hd);
+  if (sym < 0 || sym > 11) return OVM_ERR_INVALID;
+  if (sym) pred += extend(br.get(sym), sym);
+  blk[0] = (int16_t)(pred * (1 << Al));
+  return OVM_OK;
+}
+
+inline int prog_ac_first(BitReader& br, const Huff& ha, int16_t* blk, int Ss, int Se, int Al, int& eobrun) {
+  if (eobrun > 0) { --eobrun; return OVM_OK; }            // inside a run of blocks whose band is all zero
+  for (int k = Ss; k <= Se; ++k) {
+    const int rs = decode_symbol(br, ha);
+    if (rs < 0) return OVM_ERR_INVALID;
+    const int r = rs >> 4, sz = rs & 15;
+    if (sz) {
+      k += r;
+      if (k > Se) return OVM_ERR_INVALID;
+      blk[kZigzag[k]] = (int16_t)(extend(br.get(sz), sz) * (1 << Al));
+    } else if (r == 15) {
+      k += 15;                                             // ZRL
+    } else {
+      eobrun = 1 << r;                                     // EOBr: this block and eobrun - 1 more end here
+      if (r) eobrun += br.get(r);
+      --eobrun;
+      break;
+    }
+  }
+  return OVM_OK;
+}
+
+inline void prog_refine_nonzero(BitReader& br, int16_t* c, int p1) {      // one correction bit for an already-nonzero coefficient
+  if (br.get(1) && (*c & p1) == 0) *c = (int16_t)(*c >= 0 ? *c + p1 : *c - p1);
+}
+
+inline int prog_ac_refine(BitReader& br, const Huff& ha, int16_t* blk, int Ss, int Se, int Al, int& eobrun) {
+  const int p1 = 1 << Al;
+  int k = Ss;
+  if (eobrun == 0) {
+    for (; k <= Se; ++k) {
+      const int rs = decode_symbol(br, ha);
+      if (rs < 0) return OVM_ERR_INVALID;
+      int r = rs >> 4, sz = rs & 15, val = 0;
+      if (sz) {
+        if (sz != 1) return OVM_ERR_INVALID;               // a newly nonzero coefficient is +-1 at this bit position
+        val = br.get(1) ? p1 : -p1;
+      } else if (r != 15) {
+        eobrun = 1 << r;
+        if (r) eobrun += br.get(r);
+        break;                                             // the rest of the band: correction bits only (below)
+      }
+      // walk over r still-zero coefficients, refining the nonzero ones passed on the way
+      for (; k <= Se; ++k) {
+        int16_t* c = blk + kZigzag[k];
+        if (*c != 0) prog_refine_nonzero(br, c, p1);
+        else if (--r < 0) break;
+      }
+      if (val) {
+        if (k > Se) return OVM_ERR_INVALID;
+        blk[kZigzag[k]] = (int16_t)val;
+      }
+    }
+  }
+  if (eobrun > 0) {
+    for (; k <= Se; ++k) {
+      int16_t* c = blk + kZigzag[k];
+      if (*c != 0) prog_refine_nonzero(br, c, p1);
+    }
+    --eobrun;
+  }
+  return OVM_OK;
+}
+
 struct Frame {
   OvmJpegInfo info;
   int cid[3] = {0, 0, 0};
@@ -112,6 +186,8 @@ struct Frame {
   int restart = 0;
   Huff dc[4], ac[4];
   bool have_sof = false, jfif = false, adobe = false; int adobe_transform = -1;
+  bool progressive = false;
+  signed char cbits[3][64];             // progressive: bit position each coefficient has been received down to (-1: never)
 };
 
 inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
@@ -133,8 +209,10 @@ inline int parse(const uint8_t* d, size_t n, Frame& f, int16_t* coef) {
     const int len = be16(d + pos);
     if (len < 2 || pos + len > n) return OVM_ERR_INVALID;
     const uint8_t* s = d + pos + 2; const int sl = len - 2;
-    if (m == 0xC0 || m == 0xC1) {
+    if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
       if (f.have_sof || sl < 6) return OVM_ERR_INVALID;
+      f.progressive = (m == 0xC2);
+      memset(f.cbits, -1, sizeof(f.cbits));
       if (s[0] != 8) return OVM_ERR_UNSUPPORTED;
       OvmJpegInfo& I = f.info;
       I.height = be16(s + 1); I.width = be16(s + 3); I.ncomp = s[5];
@@ -192,8 +270,8 @@ inline int parse(const uint8_t* d, size_t n, Frame& f, int16_t* coef) {
       if (sl >= 5 && !memcmp(s, "JFIF", 5)) f.jfif = true;
     } else if (m == 0xEE) {
       if (sl >= 12 && !memcmp(s, "Adobe", 5)) { f.adobe = true; f.adobe_transform = s[11]; }
-    } else if (m == 0xC2 || m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
-      return OVM_ERR_UNSUPPORTED;                          // progressive, lossless, differential, arithmetic
+    } else if (m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
+      return OVM_ERR_UNSUPPORTED;                          // lossless, differential, arithmetic
     } else if (m == 0xCC) {
       return OVM_ERR_UNSUPPORTED;                          // arithmetic conditioning
     } else if (m == 0xDA) {
@@ -209,9 +287,22 @@ inline int parse(const uint8_t* d, size_t n, Frame& f, int16_t* coef) {
         for (int q = 0; q < I.ncomp; ++q) if (f.cid[q] == s[1 + 2 * i]) c = q;
         if (c < 0) return OVM_ERR_INVALID;
         sc[i] = c; td[i] = s[2 + 2 * i] >> 4; ta[i] = s[2 + 2 * i] & 15;
-        if (td[i] > 3 || ta[i] > 3 || !f.dc[td[i]].present || !f.ac[ta[i]].present) return OVM_ERR_INVALID;
+        if (td[i] > 3 || ta[i] > 3) return OVM_ERR_INVALID;
       }
-      if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63 || s[3 + 2 * ns] != 0) return OVM_ERR_UNSUPPORTED;   // spectral selection = progressive
+      const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
+      if (!f.progressive) {
+        if (Ss != 0 || Se != 63 || Ah != 0 || Al != 0) return OVM_ERR_INVALID;
+      } else {
+        if (Ss > Se || Se > 63 || Al > 13 || (Ah != 0 && Ah != Al + 1)) return OVM_ERR_INVALID;
+        if (Ss == 0 ? Se != 0 : ns != 1) return OVM_ERR_INVALID;       // DC scans carry only DC; AC scans one component
+        for (int i = 0; i < ns; ++i)
+          for (int k = Ss; k <= Se; ++k) f.cbits[sc[i]][k] = (signed char)Al;
+      }
+      for (int i = 0; i < ns; ++i) {
+        const bool need_dc = !f.progressive || (Ss == 0 && Ah == 0), need_ac = !f.progressive || Ss > 0;
+        if ((need_dc && !f.dc[td[i]].present) || (need_ac && !f.ac[ta[i]].present)) return OVM_ERR_INVALID;
+      }
+      int eobrun = 0;
       BitReader br; br.p = d + pos + len; br.end = d + n;
       int mx, my;                                          // MCU grid of this scan
       if (ns == 1) { mx = (I.cw[sc[0]] + 7) / 8; my = (I.ch[sc[0]] + 7) / 8; }
@@ -232,6 +323,7 @@ inline int parse(const uint8_t* d, size_t n, Frame& f, int16_t* coef) {
             br.p = q + 2; br.hit_marker = false;
             next_rst = (next_rst + 1) & 7;
             dcpred[0] = dcpred[1] = dcpred[2] = 0;
+            eobrun = 0;
             until_restart = f.restart;
           }
           for (int i = 0; i < ns; ++i) {
@@ -242,6 +334,17 @@ inline int parse(const uint8_t* d, size_t n, Frame& f, int16_t* coef) {
               for (int h = 0; h < nh; ++h) {
                 const int by = yy * nv + v, bx = xx * nh + h;
                 int16_t* blk = coef + (f.plane_off[c] + (size_t)by * I.bw[c] + bx) * 64;
+                if (f.progressive) {
+                  int rc = OVM_OK;
+                  if (Ss == 0) {
+                    if (Ah == 0) rc = prog_dc_first(br, hd, blk, dcpred[c], Al);
+                    else if (br.get(1)) blk[0] = (int16_t)(blk[0] | (1 << Al));
+                  } else {
+                    rc = Ah == 0 ? prog_ac_first(br, ha, blk, Ss, Se, Al, eobrun) : prog_ac_refine(br, ha, blk, Ss, Se, Al, eobrun);
+                  }
+                  if (rc) return rc;
+                  continue;
+                }
                 int sym = decode_symbol(br, hd);
                 if (sym < 0 || sym > 11) return OVM_ERR_INVALID;
                 if (sym) dcpred[c] += extend(br.get(sym), sym);
@@ -280,6 +383,10 @@ inline int parse(const uint8_t* d, size_t n, Frame& f, int16_t* coef) {
   }
   if (!f.have_sof) return OVM_ERR_INVALID;
   OvmJpegInfo& I = f.info;
+  if (f.progressive && coef)                               // every coefficient of every component down to bit 0? (an incomplete
+    for (int c = 0; c < I.ncomp; ++c)                      // progression is what libjpeg smooths across blocks: not reproduced here)
+      for (int k = 0; k < 64; ++k)
+        if (f.cbits[c][k] != 0) return OVM_ERR_UNSUPPORTED;
   if (I.ncomp == 1) I.colorspace = 0;
   else if (f.jfif) I.colorspace = 1;
   else if (f.adobe) I.colorspace = f.adobe_transform == 0 ? 2 : 1;

@@ -6,7 +6,7 @@ The reference reads images with ``cv2.imread`` (demo/demo.py:52) and detectron2'
 chroma upsampling and the colour transform run in libovm3d on the device (``ovm_jpeg_reconstruct``), bit-identical to Pillow's
 ``Image.open(f).convert("RGB")``, and the image is born in HBM where the resize kernel and the patch gather read it.
 
-Streams outside the decoder's scope (progressive, arithmetic-coded, CMYK, 4:4:0 ...) raise :class:`UnsupportedJpeg`;
+Baseline and progressive files are covered; streams outside the scope (arithmetic-coded, CMYK, 4:4:0, an incomplete progression ...) raise :class:`UnsupportedJpeg`;
 :func:`read_image_device` then hands that file, like a PNG, to the host reader and uploads the pixels."""
 from __future__ import annotations
 
@@ -32,7 +32,7 @@ def jpeg_info(data: bytes) -> "_lib.OvmJpegInfo":
     buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
     rc = L.ovm_host_jpeg_info(C.addressof(buf), len(data), C.byref(info))
     if rc == OVM_ERR_UNSUPPORTED:
-        raise UnsupportedJpeg("JPEG outside the device decoder's scope (progressive / arithmetic / 12-bit / CMYK / unusual sampling)")
+        raise UnsupportedJpeg("JPEG outside the device decoder's scope (arithmetic / 12-bit / CMYK / unusual sampling)")
     _lib.check(rc, what="ovm_host_jpeg_info")
     return info
 
@@ -70,7 +70,7 @@ def decode_jpeg(data: bytes, device: torch.device) -> torch.Tensor:
 
 def read_image_device(path: str, fmt: str, device: torch.device) -> torch.Tensor:
     """uint8 [H, W, 3] on the device in RGB or BGR channel order (``fmt``; BGR = cv2.imread's order, demo/demo.py:52). Baseline JPEGs are
-    reconstructed on the device; other formats (PNG, progressive JPEG ...) are read by the host reader and uploaded."""
+    reconstructed on the device; other formats (PNG, CMYK JPEG ...) are read by the host reader and uploaded."""
     with open(path, "rb") as f:
         data = f.read()
     img = None

@@ -50,6 +50,14 @@ CASES = [
     ("420_restart_rows", (130, 170), dict(quality=80, subsampling=2, restart_marker_rows=1)),
     ("444_restart_blocks", (40, 90), dict(quality=80, subsampling=0, restart_marker_blocks=3)),
     ("420_q5_16bit_tables", (64, 64), dict(quality=1, subsampling=2)),
+    # progressive (SOF2): DC / AC first scans and refinements, EOB runs, spectral bands - Pillow writes libjpeg's standard script
+    ("prog_420_q75", (75, 101), dict(quality=75, subsampling=2, progressive=True)),
+    ("prog_444_q90", (61, 83), dict(quality=90, subsampling=0, progressive=True)),
+    ("prog_422_optimised", (64, 97), dict(quality=60, subsampling=1, progressive=True, optimize=True)),
+    ("prog_420_restart_rows", (130, 170), dict(quality=80, subsampling=2, progressive=True, restart_marker_rows=1)),
+    ("prog_420_q100", (48, 64), dict(quality=100, subsampling=2, progressive=True)),
+    ("prog_420_q5_long_eob_runs", (200, 333), dict(quality=5, subsampling=2, progressive=True)),
+    ("prog_tiny", (9, 3), dict(quality=85, subsampling=2, progressive=True)),
 ]
 
 
@@ -70,10 +78,11 @@ def test_host_entropy_decode_and_restatement_equal_pillow(name, hw, kw):
 
 def test_grey_and_coco_example_equal_pillow():
     from oracle import jpeg_ref
-    grey = _jpeg(_scene(77, 53, 3)[:, :, 0], quality=80)
-    coef, info = gpu_jpeg.entropy_decode(grey)
-    assert info.ncomp == 1 and info.colorspace == 0
-    assert np.array_equal(jpeg_ref.reconstruct(coef.numpy(), info), _pil(grey))
+    for prog in (False, True):
+        grey = _jpeg(_scene(77, 53, 3)[:, :, 0], quality=80, progressive=prog)
+        coef, info = gpu_jpeg.entropy_decode(grey)
+        assert info.ncomp == 1 and info.colorspace == 0
+        assert np.array_equal(jpeg_ref.reconstruct(coef.numpy(), info), _pil(grey))
     data = open(COCO, "rb").read()
     coef, info = gpu_jpeg.entropy_decode(data)
     ref = _pil(data)
@@ -83,8 +92,12 @@ def test_grey_and_coco_example_equal_pillow():
 
 def test_scope_and_errors():
     arr = _scene(40, 40, 1)
+    # a progressive file whose last scan is missing: libjpeg would smooth across blocks - refused, not approximated
+    prog = _jpeg(arr, progressive=True)
+    cut = prog[:prog.rindex(b"\xff\xda")] + b"\xff\xd9"
+    assert gpu_jpeg.jpeg_info(cut).width == 40
     with pytest.raises(gpu_jpeg.UnsupportedJpeg):
-        gpu_jpeg.jpeg_info(_jpeg(arr, progressive=True))
+        gpu_jpeg.entropy_decode(cut)
     cmyk = io.BytesIO()
     Image.fromarray(np.dstack([arr, arr[:, :, :1]]), mode="CMYK").save(cmyk, format="JPEG")
     with pytest.raises(gpu_jpeg.UnsupportedJpeg):
@@ -102,16 +115,18 @@ def test_scope_and_errors():
 
 
 def test_corrupt_streams_are_refused_or_decoded_never_worse():
-    """The host half parses untrusted files: byte flips, truncations and spliced garbage must end in an error code or in a
+    """The host half parses untrusted files (baseline and progressive): byte flips, truncations and spliced garbage must end in an error code or in a
     decode of the declared size - never in a crash or an out-of-range write (the coefficient buffer is guarded by canaries)."""
     import ctypes as C
     from ovmono3d_amd import lib as _lib
     L = _lib.load()
     rng = np.random.default_rng(0)
     seeds = [_jpeg(_scene(40, 56, 2), quality=80, subsampling=2), _jpeg(_scene(33, 20, 3), quality=60, subsampling=0, restart_marker_blocks=2),
-             _jpeg(_scene(24, 24, 4)[:, :, 0], quality=70, optimize=True), open(COCO, "rb").read()[:6000]]
+             _jpeg(_scene(24, 24, 4)[:, :, 0], quality=70, optimize=True), open(COCO, "rb").read()[:6000],
+             _jpeg(_scene(40, 56, 5), quality=70, subsampling=2, progressive=True),
+             _jpeg(_scene(33, 47, 6), quality=90, subsampling=0, progressive=True, restart_marker_rows=1)]
     outcomes = {0: 0}
-    for it in range(400):
+    for it in range(600):
         data = bytearray(seeds[it % len(seeds)])
         kind = it % 4
         if kind == 0:
@@ -162,7 +177,8 @@ def test_device_decode_coco_example_grey_and_reader(device, tmp_path):
     from ovmono3d_amd.data.feeding import read_image
     p1, p2, p3 = str(tmp_path / "a.jpg"), str(tmp_path / "b.jpg"), str(tmp_path / "c.png")
     open(p1, "wb").write(data)
-    open(p2, "wb").write(_jpeg(_scene(60, 80, 4), progressive=True))
+    cm = io.BytesIO(); Image.fromarray(np.dstack([_scene(60, 80, 4), _scene(60, 80, 4)[:, :, :1]]), mode="CMYK").save(cm, format="JPEG")
+    open(p2, "wb").write(cm.getvalue())                                    # outside the scope: host reader + upload
     Image.fromarray(_scene(31, 47, 5)).save(p3)
     for p in (p1, p2, p3):
         for fmt in ("RGB", "BGR"):
