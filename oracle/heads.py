@@ -142,10 +142,11 @@ def cube_head_forward(x: torch.Tensor, sd, prefix="roi_heads.cube_head."):
     lin = lambda n: F.linear(f, sd[prefix + n + ".weight"], sd[prefix + n + ".bias"])
     deltas = lin("bbox_3D_center_deltas")
     dims = lin("bbox_3D_dims")
-    pose = rotation_6d_to_matrix(lin("bbox_3D_pose").view(-1, 6))
+    pose6 = lin("bbox_3D_pose").view(-1, 6)
+    pose = rotation_6d_to_matrix(pose6)
     z = lin("bbox_3D_center_depth")
     uncert = lin("bbox_3D_uncertainty").clip(0.01)
-    return deltas, z, dims, pose, uncert, f
+    return deltas, z, dims, pose, uncert, f, pose6
 
 
 def forward_cube(sd, feats: List[torch.Tensor], instances: List[Dict[str, torch.Tensor]], Ks: List[torch.Tensor],
@@ -174,7 +175,7 @@ def forward_cube(sd, feats: List[torch.Tensor], instances: List[Dict[str, torch.
     ctr_x = src[:, 0] + 0.5 * src_w
     ctr_y = src[:, 1] + 0.5 * src_h
 
-    deltas, z, dims, pose, uncert, fc_feat = cube_head_forward(cube_features, sd)
+    deltas, z, dims, pose, uncert, fc_feat, pose6 = cube_head_forward(cube_features, sd)
     uncert = uncert[:, 0]
     cube_x = ctr_x + src_w * deltas[:, 0]                                # roi_heads.py:480-481
     cube_y = ctr_y + src_h * deltas[:, 1]
@@ -191,8 +192,9 @@ def forward_cube(sd, feats: List[torch.Tensor], instances: List[Dict[str, torch.
     conf = torch.exp(-uncert)                                             # :807
     cube_3D = torch.cat((cube_3D, conf.unsqueeze(1)), dim=1)
     out = []
-    for c3, ps, inst in zip(cube_3D.split(nums), pose.split(nums), instances):
+    for c3, ps, p6, inst in zip(cube_3D.split(nums), pose.split(nums), pose6.split(nums), instances):
         o = dict(inst)
+        o["_pose6d"] = p6                                                 # diagnostic only (tests/parity.py: conditioning of the 6-D -> R map)
         if "scores" in o:
             o["scores"] = (o["scores"] * c3[:, -1]) ** (1 / 2)            # :825
         else:

@@ -78,7 +78,7 @@ struct OvmHandle {
   float* X = nullptr;
   Split PA, HN, AO, F1, Q, Kx, Vt, DT, DT4, DF, CT, CT4a, CT4b;
   float *dtok = nullptr, *FUS = nullptr;
-  Split RF, H1, H2; float* HO = nullptr;
+  Split RF, H1, H2; float* HO = nullptr; int lastN = 0;
   float* rec = nullptr; int* keep = nullptr;
   int *d_bidx = nullptr;
   ImageDesc* d_imgs = nullptr; ImageMeta* d_meta = nullptr;
@@ -608,6 +608,21 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
   h->D = c.embed_dim; h->C = c.fpn_channels;
   h->G = c.canvas / h->patch; h->G2 = h->G * h->G; h->T = h->G2 + (sam ? 0 : 1); h->Tpad = (h->T + 63) / 64 * 64;
   const int D = h->D, C = h->C, G = h->G, G2 = h->G2, T = h->T, L = c.depth, B = c.max_batch, R = c.max_rois;
+  {
+    // The GEMM kernels address operands with 32-bit element offsets (gemm.hip: gemm_offsets_fit): refuse a max_batch / max_rois
+    // whose largest activation image would not fit, here, before anything is allocated - not at the first oversized launch.
+    const uint64_t il = h->npass == 3 ? 2 : 1;                       // interleaved split rows are 2K halves long
+    const uint64_t side0 = (uint64_t)(p16 ? 4 : 2) * G + 2;          // finest pyramid level, zero-bordered
+    const uint64_t worst[] = {(uint64_t)B * T * 4 * D * il,          // fc2's input (GELU output), the longest activation rows
+                              (uint64_t)B * G2 * h->Kpe,             // patch rows
+                              (uint64_t)B * side0 * side0 * C * 2,   // 3x3 implicit-GEMM image (int offsets, doubled: limit 2^31 elements)
+                              (uint64_t)B * R * C * c.pooler_res * c.pooler_res};   // RoI features, fc1's input
+    for (uint64_t w : worst)
+      if (w > (1ull << 32)) {
+        h->err = "max_batch / max_rois too large: an activation image would exceed the GEMM kernels' 32-bit element offsets";
+        return OVM_ERR_CAPACITY;
+      }
+  }
   WeightMap wm;
   for (int i = 0; i < n_weights; ++i) wm.m[weights[i].name] = &weights[i];
   int r;
@@ -1050,6 +1065,7 @@ int ovm_cube_forward(OvmHandle* h, const OvmImage* images, int32_t B, const floa
   }
   fill_meta(h, images, B);
   HCHECK(h, hipMemcpyAsync(h->d_meta, h->h_meta, sizeof(ImageMeta) * B, hipMemcpyHostToDevice, s));
+  h->lastN = n;
   const int F = h->cfg.fc_dim;
   RoiParams rp; roi_params(h, &rp);
   rp.boxes = boxes; rp.batch_idx = image_idx; rp.n = n; rp.Ohi = h->RF.hi; rp.Olo = h->RF.lo; rp.ldo = h->roiK;
@@ -1115,29 +1131,12 @@ int ovm_rpn_box_forward(OvmHandle* h, const OvmImage* images, int32_t B, float* 
 // network, phrase scores, threshold, NMS, class index: roi_heads_gdino.py:93-171) -> _forward_cube -> detector_postprocess).
 // The detector runs on an internal side stream beside the backbone (it reads only the input image); the caller's stream joins it
 // before the output glue. One host synchronisation (the number of kept 2D boxes sizes the cube-head launch).
-int ovm_infer(OvmHandle* h, OvmGdino* g, const OvmImage* image, const int32_t* token_ids, int32_t ntok, const int32_t* spans,
-              int32_t n_phrases, float box_threshold, float nms_threshold, OvmDet3D* out, int32_t out_capacity, int32_t* n_out,
-              ovm_stream_t stream) {
-  if (!h || !g || !image || !token_ids || !out || !n_out) return OVM_ERR_INVALID;
-  h->err.clear();
+// Everything of ovm_infer behind its argument checks: fork, the two networks, join, glue, cube head. Split off so that EVERY error exit
+// (a failed detector or backbone launch, an allocation, the capacity check) passes through one place that drains both streams.
+static int infer_forked(OvmHandle* h, OvmGdino* g, const OvmImage* image, const int32_t* token_ids, int32_t ntok, const int32_t* spans,
+                        int32_t n_phrases, float box_threshold, float nms_threshold, OvmDet3D* out, int32_t out_capacity, int32_t* n_out,
+                        ovm_stream_t stream, int nq) {
   hipStream_t s = (hipStream_t)stream;
-  HCHECK(h, hipSetDevice(h->device));
-  if (!h->side) {
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    HCHECK(h, hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi));      // short kernels: let them jump the ViT's queue
-    HCHECK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    HCHECK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-  }
-  const int nq = ovm_gdino_num_queries(g);
-  if (nq <= 0) { h->err = "bad detector handle"; return OVM_ERR_INVALID; }
-  if (nq > h->cfg.max_rois * h->cfg.max_batch) { h->err = "detector queries exceed max_rois"; return OVM_ERR_CAPACITY; }
-  if (h->inf_cap < nq) {
-    int r;
-    if ((r = dalloc(h, &h->inf_boxes, (size_t)nq * 4)) || (r = dalloc(h, &h->inf_scores, (size_t)nq)) || (r = dalloc(h, &h->inf_classes, (size_t)nq)) ||
-        (r = dalloc(h, &h->inf_idx, (size_t)nq, true)) || (r = dalloc(h, &h->inf_n, 1)) || (r = dalloc(h, &h->inf_counts, 1))) return r;
-    h->inf_cap = nq;
-  }
   // fork: detector on the side stream
   HCHECK(h, hipEventRecord(h->ev_fork, s));
   HCHECK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
@@ -1178,6 +1177,39 @@ int ovm_infer(OvmHandle* h, OvmGdino* g, const OvmImage* image, const int32_t* t
   HCHECK(h, hipStreamSynchronize(s));
   *n_out = h->inf_host[1];
   return OVM_OK;
+}
+
+int ovm_infer(OvmHandle* h, OvmGdino* g, const OvmImage* image, const int32_t* token_ids, int32_t ntok, const int32_t* spans,
+              int32_t n_phrases, float box_threshold, float nms_threshold, OvmDet3D* out, int32_t out_capacity, int32_t* n_out,
+              ovm_stream_t stream) {
+  if (!h || !g || !image || !token_ids || !out || !n_out) return OVM_ERR_INVALID;
+  h->err.clear();
+  hipStream_t s = (hipStream_t)stream;
+  HCHECK(h, hipSetDevice(h->device));
+  if (!h->side) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    HCHECK(h, hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi));      // short kernels: let them jump the ViT's queue
+    HCHECK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HCHECK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  }
+  const int nq = ovm_gdino_num_queries(g);
+  if (nq <= 0) { h->err = "bad detector handle"; return OVM_ERR_INVALID; }
+  if (nq > h->cfg.max_rois * h->cfg.max_batch) { h->err = "detector queries exceed max_rois"; return OVM_ERR_CAPACITY; }
+  if (h->inf_cap < nq) {
+    int r;
+    if ((r = dalloc(h, &h->inf_boxes, (size_t)nq * 4)) || (r = dalloc(h, &h->inf_scores, (size_t)nq)) || (r = dalloc(h, &h->inf_classes, (size_t)nq)) ||
+        (r = dalloc(h, &h->inf_idx, (size_t)nq, true)) || (r = dalloc(h, &h->inf_n, 1)) || (r = dalloc(h, &h->inf_counts, 1))) return r;
+    h->inf_cap = nq;
+  }
+  const int r_all = infer_forked(h, g, image, token_ids, ntok, spans, n_phrases, box_threshold, nms_threshold, out, out_capacity, n_out, stream, nq);
+  if (r_all != OVM_OK) {
+    // The detector may still be running on the side stream, reading the caller's image and the plan arena: the caller is entitled to
+    // free or reuse the image once this call has returned, and the next call's fork must not race with leftover work on h->inf_*.
+    (void)hipStreamSynchronize(h->side);
+    (void)hipStreamSynchronize(s);
+  }
+  return r_all;
 }
 
 // Co-run mode: the caller runs other work (the GroundingDINO detector) on a second stream while ovm_backbone_forward executes. The
@@ -1247,6 +1279,12 @@ int64_t ovm_debug_copy(OvmHandle* h, const char* name, float* dst, int64_t capac
     const FpnLevel& f = h->lv[k[1] - '2'];
     src = f.p; n = (int64_t)B * f.side * f.side * C;
   }
+  // the RPN's per-image proposals after top-k / NMS (boxes [B][R][4], objectness logits [B][R], counts [B] as int32 bits) and the
+  // cube head's raw outputs of the last ovm_cube_forward ([n][16]: deltas 2, dims 3, pose 6, depth 1, uncertainty 1) - parity tests
+  else if (k == "rpn_boxes" && h->has_rpn && h->has_box) { src = h->det.prop_boxes; n = (int64_t)B * h->det.R * 4; }
+  else if (k == "rpn_scores" && h->has_rpn && h->has_box) { src = h->det.prop_scores; n = (int64_t)B * h->det.R; }
+  else if (k == "rpn_counts" && h->has_rpn && h->has_box) { src = (const float*)h->det.prop_count; n = B; }
+  else if (k == "cube_head") { src = h->HO; n = (int64_t)h->lastN * 16; }
   else { h->err = "unknown debug tensor"; return OVM_ERR_INVALID; }
   if (n > capacity) { h->err = "debug copy capacity too small"; return OVM_ERR_CAPACITY; }
   if (hipMemcpyAsync(dst, src, (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return OVM_ERR_HIP;

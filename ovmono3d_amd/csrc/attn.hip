@@ -728,6 +728,7 @@ int launch_attention(const AttnParams& p, int npass, hipStream_t s) {
       constexpr int smem_pp = 2 * 4 * 2 * 64 * 128;        // two 4-slot rings of hi + lo tiles = 128 KiB
       static bool setpp = false;
       if (!setpp) { (void)hipFuncSetAttribute((const void*)attn_pp_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); setpp = true; }
+#ifdef OVM_DIAG      // in-kernel s_memtime stamps and the timing-only ablations (STAMP 2 / 3 give WRONG results): diagnostic builds only
       if (pm.stamps) {
         (void)hipFuncSetAttribute((const void*)attn_pp_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)attn_pp_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -736,6 +737,7 @@ int launch_attention(const AttnParams& p, int npass, hipStream_t s) {
         else if (g_attn_pp == 3) hipLaunchKernelGGL((attn_pp_kernel<3, 3>), grid, block, smem_pp + 8192, s, pm);
         else hipLaunchKernelGGL((attn_pp_kernel<3, 1>), grid, block, smem_pp + 8192, s, pm);
       } else
+#endif
       hipLaunchKernelGGL((attn_pp_kernel<3>), grid, block, smem_pp + pad, s, pm);
     } else if (nw == 8) {
       static bool set8 = false;

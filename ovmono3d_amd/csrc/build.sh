@@ -5,6 +5,8 @@ cd "$(dirname "$0")"
 OUT=../libovm3d.so
 mkdir -p build
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+# OVM_DIAG=1: diagnostic build (in-kernel s_memtime stamps and the timing-only attention ablations of scratch/; never shipped) - delete build/ when switching
+if [ -n "$OVM_DIAG" ]; then FLAGS="$FLAGS -DOVM_DIAG"; fi
 pids=()
 for f in gemm gemm256 gemm_small elementwise attn roi_cube det2d ops gops gdino_kernels gdino box3d resize jpeg api; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ -n "$(find . -maxdepth 1 -name '*.hpp' -newer build/$f.o)" ] || [ ../../include/ovm3d.h -nt build/$f.o ]; then

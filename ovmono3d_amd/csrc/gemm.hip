@@ -137,8 +137,27 @@ static int launch_prec(const GemmParams& p, int npass, hipStream_t s) {
   return st == 3 ? launch_one<1, 64, 128, 3, EPI, AMODE>(p, s) : launch_one<1, 64, 128, 2, EPI, AMODE>(p, s);
 }
 
+// The kernels address their operands with 32-bit ELEMENT offsets (gemm.hpp a_row_offset / woff, gemm256.hip aoff / woff:
+// uint32 counts of halves; the implicit-GEMM row offset is formed in int): the last element a launch can touch must stay
+// below 2^32 (2^31 for the convolution image). ViT-L, T = 5477, batch 64, interleaved fc2 input (lda 8192) = 2.87e9: inside;
+// the next size up is refused here instead of wrapping around silently.
+bool gemm_offsets_fit(const GemmParams& p, int npass, int amode) {
+  const uint64_t lim = 1ull << 32;
+  const uint64_t ldw = (npass == 3) ? 2ull * p.K : (uint64_t)p.K;
+  const uint64_t npad = ((uint64_t)p.N + 255) / 256 * 256;           // weights are padded to whole tiles of either kernel
+  if (npad * ldw > lim) return false;
+  if (amode == A_CONV3X3) {
+    if (p.cH <= 0 || p.cW <= 0 || p.cC <= 0) return false;
+    const uint64_t Bn = ((uint64_t)p.M + (uint64_t)p.cH * p.cW - 1) / ((uint64_t)p.cH * p.cW);
+    return Bn * (p.cH + 2) * (p.cW + 2) * (uint64_t)p.cC <= (1ull << 31);
+  }
+  const uint64_t rowlen = (npass == 3 && p.a_il) ? 2ull * p.K : (uint64_t)p.K;
+  return (uint64_t)(p.M > 0 ? p.M - 1 : 0) * (uint64_t)p.lda + rowlen <= lim;
+}
+
 int launch_gemm(const GemmParams& p, int npass, int epi, int amode, hipStream_t s) {
   if (npass == 3 && (p.Alo == nullptr || p.Wlo == nullptr)) return OVM_ERR_INVALID;
+  if (!gemm_offsets_fit(p, npass, amode)) return OVM_ERR_CAPACITY;
   if (amode == A_CONV3X3) {
     if (epi != EPI_STORE) return OVM_ERR_INVALID;
     return launch_prec<EPI_STORE, A_CONV3X3>(p, npass, s);

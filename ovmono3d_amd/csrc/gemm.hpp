@@ -681,6 +681,8 @@ __device__ __forceinline__ void gemm_tail_body(const GemmParams& p, int tb) {
 
 // Host launcher (defined in gemm.hip). npass in {1,3}.
 int launch_gemm(const GemmParams& p, int npass, int epi, int amode, hipStream_t stream);
+// false when an operand offset of this launch would not fit the kernels' 32-bit element offsets (launchers then return OVM_ERR_CAPACITY)
+bool gemm_offsets_fit(const GemmParams& p, int npass, int amode);
 // gemm256.hip: 256 x 256 tiles, two wave groups ping-ponging LOAD / COMPUTE; needs interleaved A and W images, N % 256 == 0
 bool gemm256_supported(const GemmParams& p, int npass);
 int launch_gemm256(const GemmParams& p, int epi, int ksplit_hint, hipStream_t stream);

@@ -321,6 +321,7 @@ bool gemm256_supported(const GemmParams& p, int npass) {
 int launch_gemm256(const GemmParams& p, int epi, int ksplit_hint, hipStream_t s) {
   if (!gemm256_supported(p, 3)) return OVM_ERR_INVALID;
   if (p.M <= 0 || p.N <= 0) return OVM_OK;
+  if (!gemm_offsets_fit(p, 3, A_ROWMAJOR)) return OVM_ERR_CAPACITY;
   switch (epi) {
     case EPI_STORE: return launch256<EPI_STORE>(p, ksplit_hint, s);
     case EPI_RESID: return launch256<EPI_RESID>(p, ksplit_hint, s);

@@ -56,7 +56,12 @@ struct Huff {
 struct BitReader {
   const uint8_t* p; const uint8_t* end;
   uint64_t acc = 0; int n = 0;         // n valid bits at the bottom of acc
+  int pad = 0;                         // how many of them (the lowest) are phantom zeros appended behind a marker / the end of the data
   bool hit_marker = false;
+  // The look-ahead of peek() may run into the phantom bits; CONSUMING one means the entropy-coded data ended before the scan did:
+  // a truncated or cut file. libjpeg pads such a stream with zeros under a warning, Pillow (the reference's reader) raises on it -
+  // so does this decoder (checked once per block by the scan loop).
+  inline bool exhausted() const { return n < pad; }
   void fill() {
     if (!hit_marker && p + 8 <= end) {                             // whole bytes at once while no 0xFF is near
       uint64_t v; memcpy(&v, p, 8);
@@ -73,20 +78,22 @@ struct BitReader {
     }
     while (n <= 56) {
       uint8_t b = 0;
+      bool real = false;
       if (!hit_marker && p < end) {
         b = *p;
         if (b == 0xFF) {
-          if (p + 1 < end && p[1] == 0x00) p += 2;            // stuffed byte
-          else { hit_marker = true; b = 0; }                   // a marker ends the segment: zeros from here on (as libjpeg)
-        } else ++p;
+          if (p + 1 < end && p[1] == 0x00) { p += 2; real = true; }   // stuffed byte
+          else { hit_marker = true; b = 0; }                           // a marker ends the segment: zeros from here on (as libjpeg)
+        } else { ++p; real = true; }
       } else hit_marker = hit_marker || p >= end;
+      if (!real) pad += 8;
       acc = (acc << 8) | b; n += 8;
     }
   }
   inline int peek(int k) { if (n < k) fill(); return (int)((acc >> (n - k)) & ((1u << k) - 1)); }
   inline void skip(int k) { n -= k; }
   inline int get(int k) { const int v = peek(k); n -= k; return v; }
-  void reset() { acc = 0; n = 0; }
+  void reset() { acc = 0; n = 0; pad = 0; }
 };
 
 inline int decode_symbol(BitReader& br, const Huff& h) {
@@ -187,6 +194,8 @@ struct Frame {
   Huff dc[4], ac[4];
   bool have_sof = false, jfif = false, adobe = false; int adobe_transform = -1;
   bool progressive = false;
+  int n_scans = 0;
+  int orientation = 1;                  // Exif Orientation of APP1 (1 = as stored)
   signed char cbits[3][64];             // progressive: bit position each coefficient has been received down to (-1: never)
 };
 
@@ -198,12 +207,13 @@ inline int parse(const uint8_t* d, size_t n, Frame& f, int16_t* coef) {
   memset(&f.info, 0, sizeof(f.info));
   size_t pos = 2;
   int dcpred[3];
-  while (pos + 4 <= n) {
+  bool saw_sos = false, saw_eoi = false;
+  while (pos + 2 <= n) {
     if (d[pos] != 0xFF) return OVM_ERR_INVALID;
     while (pos < n && d[pos] == 0xFF) ++pos;              // fill bytes
     if (pos >= n) return OVM_ERR_INVALID;
     const int m = d[pos++];
-    if (m == 0xD9) break;                                 // EOI
+    if (m == 0xD9) { saw_eoi = true; break; }             // EOI
     if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;  // standalone
     if (pos + 2 > n) return OVM_ERR_INVALID;
     const int len = be16(d + pos);
@@ -236,7 +246,9 @@ inline int parse(const uint8_t* d, size_t n, Frame& f, int16_t* coef) {
         I.cw[c] = (I.width * I.h[c] + I.hmax - 1) / I.hmax; I.ch[c] = (I.height * I.v[c] + I.vmax - 1) / I.vmax;
         f.plane_off[c] = off; off += (size_t)I.bw[c] * I.bh[c];
       }
-      if (off > ((size_t)1 << 22)) return OVM_ERR_UNSUPPORTED;           // > 2^28 samples (a 16k x 16k image): refuse rather than allocate gigabytes for a header
+      // Pillow's MAX_IMAGE_PIXELS (the size above which the reference's reader warns of a decompression bomb): beyond it the file
+      // goes to the host reader and its policy instead of pinning hundreds of MB for a 100-byte header
+      if ((int64_t)I.width * I.height > 89478485 || off > ((size_t)1 << 22)) return OVM_ERR_UNSUPPORTED;
       I.coef_blocks = (int32_t)off;
       f.have_sof = true;
     } else if (m == 0xC4) {
@@ -268,6 +280,28 @@ inline int parse(const uint8_t* d, size_t n, Frame& f, int16_t* coef) {
       f.restart = be16(s);
     } else if (m == 0xE0) {
       if (sl >= 5 && !memcmp(s, "JFIF", 5)) f.jfif = true;
+    } else if (m == 0xE1) {
+      // APP1 "Exif": the Orientation tag (0x0112) of IFD0. Both readers of the reference apply it (cv2.imread, demo/demo.py:52;
+      // detectron2 read_image -> _apply_exif_orientation, dataset_mapper.py:38); files that carry one other than 1 are left to the
+      // host reader, which transposes (OVM_ERR_UNSUPPORTED below).
+      if (sl >= 14 && !memcmp(s, "Exif\0\0", 6)) {
+        const uint8_t* t = s + 6; const int tl = sl - 6;
+        const bool le = t[0] == 'I' && t[1] == 'I', be = t[0] == 'M' && t[1] == 'M';
+        auto r16 = [&](int o) { return le ? (t[o] | (t[o + 1] << 8)) : ((t[o] << 8) | t[o + 1]); };
+        auto r32 = [&](int o) { return le ? (uint32_t)(t[o] | (t[o + 1] << 8) | (t[o + 2] << 16)) | ((uint32_t)t[o + 3] << 24)
+                                          : ((uint32_t)t[o] << 24) | (uint32_t)((t[o + 1] << 16) | (t[o + 2] << 8) | t[o + 3]); };
+        if ((le || be) && r16(2) == 42) {
+          const uint32_t ifd = r32(4);
+          if (ifd >= 8 && ifd < (uint32_t)tl && (uint32_t)tl - ifd >= 2) {          // (compared without forming ifd + x: ifd is the file's)
+            const int cnt = r16((int)ifd);
+            const uint32_t room = (uint32_t)tl - ifd - 2;
+            for (int e = 0; e < cnt && 12u * (uint32_t)(e + 1) <= room; ++e) {
+              const int o = (int)ifd + 2 + 12 * e;
+              if (r16(o) == 0x0112 && r16(o + 2) == 3) { f.orientation = r16(o + 8); break; }
+            }
+          }
+        }
+      }
     } else if (m == 0xEE) {
       if (sl >= 12 && !memcmp(s, "Adobe", 5)) { f.adobe = true; f.adobe_transform = s[11]; }
     } else if (m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
@@ -276,8 +310,12 @@ inline int parse(const uint8_t* d, size_t n, Frame& f, int16_t* coef) {
       return OVM_ERR_UNSUPPORTED;                          // arithmetic conditioning
     } else if (m == 0xDA) {
       if (!f.have_sof) return OVM_ERR_INVALID;
+      saw_sos = true;
       if (!coef) break;                                    // header walk ends here
       const OvmJpegInfo& I = f.info;
+      // every scan walks all of its blocks even when it carries no data: bound the number of scans (libjpeg-turbo's fuzz limit is of
+      // the same order; Pillow's standard progression has 10) so that a few KB of empty SOS headers cannot cost minutes
+      if (++f.n_scans > 64 * I.ncomp) return OVM_ERR_INVALID;
       if (sl < 1) return OVM_ERR_INVALID;
       const int ns = s[0];
       if (ns < 1 || ns > I.ncomp || sl < 1 + 2 * ns + 3) return OVM_ERR_INVALID;
@@ -343,6 +381,8 @@ inline int parse(const uint8_t* d, size_t n, Frame& f, int16_t* coef) {
                     rc = Ah == 0 ? prog_ac_first(br, ha, blk, Ss, Se, Al, eobrun) : prog_ac_refine(br, ha, blk, Ss, Se, Al, eobrun);
                   }
                   if (rc) return rc;
+                  if (br.exhausted()) return OVM_ERR_INVALID;
+                  if (dcpred[c] < -65536 || dcpred[c] > 65535) return OVM_ERR_INVALID;
                   continue;
                 }
                 int sym = decode_symbol(br, hd);
@@ -367,6 +407,9 @@ inline int parse(const uint8_t* d, size_t n, Frame& f, int16_t* coef) {
                   blk[kZigzag[k]] = (int16_t)extend(br.get(sz), sz);
                   ++k;
                 }
+                if (br.exhausted()) return OVM_ERR_INVALID;               // the data ended inside this block: a truncated file
+                // the DC predictor of a valid 8-bit stream stays within 11 + 1 bits; an attacker's stream must not walk it to overflow
+                if (dcpred[c] < -65536 || dcpred[c] > 65535) return OVM_ERR_INVALID;
               }
           }
           if (until_restart > 0) --until_restart;
@@ -382,6 +425,10 @@ inline int parse(const uint8_t* d, size_t n, Frame& f, int16_t* coef) {
     pos += len;
   }
   if (!f.have_sof) return OVM_ERR_INVALID;
+  // a file that ends in its headers, or behind its scans without the EOI marker, is a cut file: Pillow (the reference's reader) raises
+  // "image file is truncated" on both
+  if (!saw_sos || (coef && !saw_eoi)) return OVM_ERR_INVALID;
+  if (f.orientation >= 2 && f.orientation <= 8) return OVM_ERR_UNSUPPORTED;      // to be transposed: the host reader's job
   OvmJpegInfo& I = f.info;
   if (f.progressive && coef)                               // every coefficient of every component down to bit 0? (an incomplete
     for (int c = 0; c < I.ncomp; ++c)                      // progression is what libjpeg smooths across blocks: not reproduced here)

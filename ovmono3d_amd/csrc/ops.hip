@@ -193,7 +193,12 @@ int ovm_tune_set(const char* key, int32_t value) {
   if (!strcmp(key, "gemm_splitk")) { gemm_set_splitk(value); return OVM_OK; }
   if (!strcmp(key, "gemm_tail")) { gemm_set_tail_rows(value); return OVM_OK; }
   if (!strcmp(key, "attn_waves")) { attn_set_waves(value); return OVM_OK; }
-  if (!strcmp(key, "attn_pp")) { attn_set_pp(value); return OVM_OK; }
+  if (!strcmp(key, "attn_pp")) {
+#ifndef OVM_DIAG
+    if (value < 0 || value > 1) return OVM_ERR_INVALID;    // 2 / 3 select timing-only ablations with wrong results: -DOVM_DIAG builds only
+#endif
+    attn_set_pp(value); return OVM_OK;
+  }
   if (!strcmp(key, "attn_prio")) { attn_set_prio(value); return OVM_OK; }
   if (!strcmp(key, "attn_lds_pad")) { attn_set_lds_pad(value); return OVM_OK; }
   if (!strcmp(key, "attn_tail")) { attn_set_tail_rows(value); return OVM_OK; }
@@ -212,7 +217,11 @@ int ovm_tune_set(const char* key, int32_t value) {
 /* diagnostics: hands a device pointer to a named debug hook ("gemm256_stamps": u64 [8][128], NULL switches it off) */
 int ovm_debug_set_ptr(const char* key, void* ptr) {
   if (key && !strcmp(key, "gemm256_stamps")) { g_gemm256_stamps = (unsigned long long*)ptr; return OVM_OK; }
+#ifdef OVM_DIAG
   if (key && !strcmp(key, "attn_stamps")) { attn_set_stamps((unsigned long long*)ptr); return OVM_OK; }
+#else
+  if (key && !strcmp(key, "attn_stamps")) return OVM_ERR_UNSUPPORTED;      // stamp / ablation kernels exist in -DOVM_DIAG builds only (OVM_DIAG=1 csrc/build.sh)
+#endif
   return OVM_ERR_INVALID;
 }
 

@@ -19,9 +19,11 @@ from .. import lib as _lib
 
 def read_image(path: str, fmt: str = "RGB") -> np.ndarray:
     """uint8 HxWx3. fmt 'BGR' mirrors cv2.imread (reference util.imread used at demo/demo.py:52)."""
-    from PIL import Image
+    from PIL import Image, ImageOps
     with Image.open(path) as im:
-        arr = np.asarray(im.convert("RGB"))
+        # both readers of the reference honour the Exif Orientation tag: cv2.imread (demo/demo.py:52) and detectron2's read_image
+        # (_apply_exif_orientation, dataset_mapper.py:38)
+        arr = np.asarray(ImageOps.exif_transpose(im).convert("RGB"))
     return arr[:, :, ::-1].copy() if fmt == "BGR" else arr
 
 

@@ -11,6 +11,41 @@ import torch
 
 FIELDS = ("pred_boxes", "scores", "pred_bbox3D", "pred_center_cam", "pred_center_2D", "pred_dimensions", "pred_pose")
 
+# "1e-3 rel" element by element needs a floor under which "relative" has no meaning for an element of the field (a rotation entry
+# that is ~0, the x of an object on the optical axis): |a_i - b_i| / max(|b_i|, floor). Floors in the field's own unit.
+ELEM_FLOOR = {"pred_boxes": 1.0,          # pixels (original resolution)
+              "scores": 1e-2,
+              "pred_bbox3D": 0.1,         # metres
+              "pred_center_cam": 0.1,     # metres
+              "pred_center_2D": 1.0,      # pixels
+              "pred_dimensions": 0.05,    # metres
+              "pred_pose": 0.1}           # entries of a rotation matrix
+
+
+def elem_rel_err(a: torch.Tensor, b: torch.Tensor, floor: float) -> float:
+    """max_i |a_i - b_i| / max(|b_i|, floor): the element-wise relative error with an absolute floor."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    if b.numel() == 0:
+        return 0.0
+    return float(((a - b).abs() / b.abs().clamp_min(floor)).max())
+
+
+def geodesic(Ra: torch.Tensor, Rb: torch.Tensor) -> torch.Tensor:
+    """Rotation angle (rad) of Ra^T Rb per detection; for small angles ||Ra - Rb||_F / sqrt(2) (no acos cancellation)."""
+    return (Ra.double() - Rb.double()).flatten(1).norm(dim=1) / (2.0 ** 0.5)
+
+
+def pose_conditioning(p6: torch.Tensor):
+    """rotation_6d_to_matrix (cube_head.py:177) divides by n1 = |a1| and n2 = |a2 - (b1.a2) b1|: a perturbation d of the head's raw
+    6-D output turns the frame by ~|d| / n1 and ~|d| / n2. Returns (n1, n2, amplification of a perturbation measured relative to the
+    vector's own length |p6|: |p6| / min(n1, n2))."""
+    p6 = p6.double()
+    a1, a2 = p6[:, :3], p6[:, 3:]
+    n1 = a1.norm(dim=1)
+    b1 = a1 / n1.clamp_min(1e-30)[:, None]
+    n2 = (a2 - (b1 * a2).sum(1, keepdim=True) * b1).norm(dim=1)
+    return n1, n2, p6.norm(dim=1) / torch.minimum(n1, n2).clamp_min(1e-30)
+
 
 def _field(inst, f):
     v = inst.get(f)
@@ -51,12 +86,44 @@ def parity_report(inst, ref: Dict[str, torch.Tensor], box_tol: float = 2e-3) -> 
     gi = pair[ok]
     gc = inst.pred_classes.detach().cpu().to(torch.int64)[gi]
     rep["class_id_mismatches"] = int((gc != ref["pred_classes"].to(torch.int64)[ok]).sum())
+    rep["max_elem_rel_err"] = {}
     for f in FIELDS:
         a, b = _field(inst, f)[gi], ref[f].double()[ok]
         rep["max_rel_err"][f] = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+        rep["max_elem_rel_err"][f] = elem_rel_err(a, b, ELEM_FLOOR[f])
+    # ---- pose, detection by detection: which ones exceed 1e-3, by how much their 2D boxes differ, and how the 6-D -> R map is
+    # conditioned there (the oracle's raw 6-D head output rides along as the diagnostic field `_pose6d`)
+    pa, pb = _field(inst, "pred_pose")[gi], ref["pred_pose"].double()[ok]
+    perr = (pa - pb).abs().flatten(1).amax(1)
+    ang = geodesic(pa, pb)
+    box_px = (gb[gi] - rb[ok]).abs().amax(1)
+    pose = {"n_over_1e-3": int((perr > 1e-3).sum()), "max_entry_err": float(perr.max()), "max_geodesic_rad": float(ang.max()),
+            "max_box_delta_px": float(box_px.max())}
+    if "_pose6d" in ref:
+        n1, n2, amp = pose_conditioning(ref["_pose6d"][ok])
+        pose["amplification_median"] = float(amp.median())
+        # the angle a 1e-3-relative perturbation of the raw 6-D vector may cause, per detection: 1e-3 x amplification
+        excess = ang / (1e-3 * amp)
+        pose["max_geodesic_over_1e-3xamp"] = float(excess.max())
+        worst = torch.argsort(perr, descending=True)[:8].tolist()
+        pose["worst"] = [{"oracle_idx": int(torch.nonzero(ok)[k]), "entry_err": float(perr[k]), "geodesic_rad": float(ang[k]),
+                          "box_delta_px": float(box_px[k]), "n1": float(n1[k]), "n2": float(n2[k]), "amplification": float(amp[k])}
+                         for k in worst if perr[k] > 1e-3]
+    rep["pose"] = pose
     return rep
 
 
-def parity_ok(rep: Dict, tol: float = 1e-3) -> bool:
-    return (rep["unmatched_oracle"] == 0 and rep["unmatched_hip"] == 0 and rep["class_id_mismatches"] == 0
-            and all(v <= tol for v in rep["max_rel_err"].values()))
+def parity_ok(rep: Dict, tol: float = 1e-3, pose_by_conditioning: bool = False) -> bool:
+    """Every paired detection, every float field within `tol` (scale-relative, tests/common.py:rel_err), ids exact, nothing unpaired.
+    pose_by_conditioning (the end-to-end leg behind a 900-query detector only - the two routes hand the cube head 2D boxes that differ
+    in the last bits): pred_pose is held to `tol` as the ANGLE a tol-relative perturbation of the head's raw 6-D output may cause at
+    that detection's own conditioning (pose_conditioning), not to a blanket looser number."""
+    if rep["unmatched_oracle"] or rep["unmatched_hip"] or rep["class_id_mismatches"]:
+        return False
+    for k, v in rep["max_rel_err"].items():
+        if k == "pred_pose" and pose_by_conditioning and "max_geodesic_over_1e-3xamp" in rep.get("pose", {}):
+            if rep["pose"]["max_geodesic_over_1e-3xamp"] * 1e-3 > tol:
+                return False
+        elif v > tol:
+            return False
+    return True

@@ -166,3 +166,21 @@ def test_rccl_gather_c_abi_one_rank(device):
     finally:
         D.set_native_comm(None)
         comm.close()
+
+
+def test_bench_gpus2_real_steps_gloo(device):
+    """`python bench.py --gpus 2` as the driver calls it (no launcher): bench.py starts its own two ranks as a child process before
+    touching the GPU, both ranks run real steps of a tiny model on this one card (OVM_BENCH_BACKEND=gloo: ranks may share a device),
+    and rank 0 prints one line with n_gpus 2 and the whole-job rate (VERDICT r2 weak #4)."""
+    env = dict(os.environ, OVM_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "OVM_BENCH_DRYRUN"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--model", "vittest14", "--canvas", "224",
+           "--net-res", "140", "--proposals", "oracle2d", "--boxes", "8", "--no-alt", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and abs(d["value"] - 2 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-2
+    assert d["scaling"] == "weak" and "dry_run" not in d

@@ -213,3 +213,45 @@ def test_ovm_infer_one_call_equals_staged_path(device, tower):
             assert torch.equal(a.get(f), b.get(f)), f
         assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor)
     assert torch.equal(outs[0][0].pred_bbox3D, outs[0][2].pred_bbox3D)      # same input -> same output across graph replays
+
+
+def test_ovm_infer_error_after_fork_leaves_the_handle_usable(device):
+    """An error behind ovm_infer's fork (here: an image larger than the backbone's canvas, refused by ovm_backbone_forward while the
+    detector already runs on the side stream) must drain both streams before it returns - the caller may free the image right away -
+    and must leave the handle usable: the next call gives the same records as a handle that never saw the error."""
+    from common import build_cfg, synth_inputs
+    from ovmono3d_amd.gdino.detector import HashTokenizer, NativeGroundingDino
+    from ovmono3d_amd.gdino.engine import GDinoConfig
+    from ovmono3d_amd.lib import OvmError
+    from ovmono3d_amd.modeling import build_model
+    from ovmono3d_amd.util.synth_weights import synth_state_dict
+    hf, _ = _small_hf_gdino()
+
+    class Tok(HashTokenizer):
+        def _id(self, w):
+            return super()._id(w) % 1900 + 50 if w not in (".", "?") else super()._id(w)
+    sd = synth_state_dict("vittest14", seed=3)
+    cfg = build_cfg("vittest14", 280, "f16x3", max_batch=1, max_rois=64, roi_heads="ROIHeads3DGDINO")
+
+    def make():
+        m = build_model(cfg, device=device)
+        m.load_state_dict(sd)
+        m.roi_heads.detector = NativeGroundingDino(device, hf.state_dict(), Tok(), cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, cfg=GDinoConfig(**SMALL))
+        return m
+
+    def inp(hw, seed):
+        d = synth_inputs(1, hw=(hw,), oracle2d=False, seed=seed)
+        d[0]["category_list"] = ["chair", "dining table", "sofa"]
+        d[0]["image"] = d[0]["image"].to(device)
+        return d
+    clean, hit = make(), make()
+    want = clean(inp((210, 280), 5))[0]["instances"]
+    for _ in range(2):
+        big = inp((294, 350), 9)                                  # wider than the 280 canvas: the detector takes it, the backbone refuses
+        with pytest.raises(OvmError):
+            hit(big)
+        del big                                                   # the image may be freed as soon as the call has returned
+        got = hit(inp((210, 280), 5))[0]["instances"]
+        assert len(got) == len(want) >= 5
+        for f in ("scores", "pred_bbox3D", "pred_pose"):
+            assert torch.equal(got.get(f), want.get(f)), f

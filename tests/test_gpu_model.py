@@ -391,3 +391,58 @@ def test_sam_vitb_canvas1024(device):
         model.backbone(model.preprocess_image(inputs))
     torch.cuda.synchronize()
     print(f"SAM ViT-B @1024 backbone: {(time.time() - t0) / 5 * 1e3:.2f} ms per image")
+
+
+# ------------------------------------------------------------------------------------------ BASELINE configs 3 / 4 / 5 at their per-GPU batch
+def _batch8_every_image(device, cfg, sd_seed, shapes, orig_scale, n_boxes, seed, label):
+    """A real batch of 8 images per GPU (BASELINE configs[2..4]: 16 / 2, 32 / 4, 64 / 8) of >= 3 distinct network shapes through
+    one call, every image checked (reference omni3d_evaluation.py:652-667 feeds the model whole batches):
+      * images 0 and 7 against the CPU oracle: ids exact, every float field within 1e-3;
+      * every image against ITS OWN batch-1 run on the HIP path: ids exact, floats within 1e-6 (scale-relative; a batch changes
+        tile / split-K assignment, i.e. fp32 summation order, never the arithmetic) - the batch-1 route is oracle-anchored by
+        test_oracle2d_vitl_canvas896_headline_size / test_clip_vitb16_canvas1024_config4_size and by images 0 and 7 here."""
+    from oracle.pipeline import inference
+    model, sd = _build(cfg, seed=sd_seed)
+    inputs = synth_inputs(8, hw=shapes, orig_scale=orig_scale, n_boxes=n_boxes, seed=seed)
+    assert len({tuple(d["image"].shape[1:]) for d in inputs}) >= 3
+    out = model(inputs)
+    assert len(out) == 8
+    worst = 0.0
+    for i in range(8):
+        solo = model([inputs[i]])[0]["instances"]
+        inst = out[i]["instances"]
+        assert len(inst) == len(solo) == n_boxes, (i, len(inst), len(solo))
+        assert torch.equal(inst.pred_classes, solo.pred_classes), f"image {i}: category indices differ between batch 8 and batch 1"
+        for f in FIELDS:
+            a, b = inst.get(f), solo.get(f)
+            a, b = (a.tensor if hasattr(a, "tensor") else a), (b.tensor if hasattr(b, "tensor") else b)
+            worst = max(worst, assert_close(a, b, 1e-6, f"image {i} {f} (batch 8 vs batch 1)"))
+    print(f"{label}: batch 8 vs batch 1 on the HIP path, worst field error over 8 images {worst:.2e}")
+    torch.set_num_threads(16)
+    ref = inference(sd, [inputs[0], inputs[7]], oracle_params(cfg))
+    _compare([out[0], out[7]], ref)
+    errs = {f: max(float((((o["instances"].get(f).tensor if hasattr(o["instances"].get(f), "tensor") else o["instances"].get(f)).cpu().double()
+                           - r[f].double()).abs().max() / r[f].double().abs().max())) for o, r in zip([out[0], out[7]], ref)) for f in FIELDS}
+    print(f"{label}: images 0 and 7 vs the CPU oracle: " + ", ".join(f"{k} {v:.1e}" for k, v in errs.items()))
+
+
+def test_config3_vitl_canvas896_batch8_every_image(device):
+    """BASELINE configs[2] (Omni3D novel-split eval, batch 16 over 2 GPUs = 8 per GPU): DINOv2 ViT-L/14, 24 layers, canvas 896
+    (T = 4097), 8 images of 4 network shapes as ResizeShortestEdge(532, 896) emits them, 16 given boxes each."""
+    cfg = build_cfg("vitl14", 896, "f16x3", max_batch=8, max_rois=64)
+    _batch8_every_image(device, cfg, 0, ((532, 532), (532, 709), (709, 532), (504, 896)), 512.0 / 532.0, 16, 71, "config 3 (ViT-L/14 @896)")
+
+
+def test_config4_clip_vitb16_canvas1024_batch8_every_image(device):
+    """BASELINE configs[3] (OVMono3D_clip_SFP.yaml, batch 32 over 4 GPUs = 8 per GPU): CLIP ViT-B/16 at canvas 1024 (T = 4097),
+    4-level pyramid, 8 images of 3 shapes."""
+    cfg = build_clip_cfg("ViT-B-16", 1024, "f16x3", max_batch=8, max_rois=64)
+    _batch8_every_image(device, cfg, 0, ((608, 800), (608, 1024), (800, 608)), 1.0, 16, 72, "config 4 (CLIP ViT-B/16 @1024)")
+
+
+def test_config5_vitl_24layers_canvas1036_batch8_every_image(device):
+    """BASELINE configs[4] (1024 x 1024 inputs, batch 64 over 8 GPUs = 8 per GPU) at its full depth: DINOv2 ViT-L/14, all 24
+    layers, SQUARE_PAD 1036 -> 74 x 74 patches, T = 5477 (partial last attention block, odd p4 = 37), 8 images of 3 shapes -
+    replaces the depth-2 stand-in of test_config5_geometry_vitl_width_canvas1036_batch2 for the full network."""
+    cfg = build_cfg("vitl14", 1036, "f16x3", max_batch=8, max_rois=64)
+    _batch8_every_image(device, cfg, 0, ((1024, 1024), (768, 1024), (1024, 683)), 1.0, 16, 73, "config 5 (ViT-L/14 x 24 @1036, T=5477)")

@@ -379,3 +379,61 @@ def test_attention_two_wave_group_kernel_is_bit_identical(device, B, T, heads):
         L.ovm_tune_set(b"attn_pp", 0)
     assert_close(outs[1][0], _attn_ref(qkv.cpu(), B, T, heads), 3e-6, "two-wave-group attention")
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[1][0], outs[1][1])
+
+
+@pytest.mark.parametrize("kernel", ["ws128", "gemm256"])
+def test_gemm_32bit_offset_boundary(device, kernel):
+    """The GEMM kernels address their operands with 32-bit element offsets (gemm.hpp a_row_offset, gemm256.hip aoff). The
+    largest launch that fits - M x lda = 2^32 halves exactly: 524,288 rows of an interleaved K = 4096 image, the fc2 input
+    layout - must still read its LAST rows correctly, and one row more must be refused with OVM_ERR_CAPACITY instead of wrapping
+    around (VERDICT r2 weak #3; ovm_create applies the same bound to max_batch, test_create_refuses_offset_overflow)."""
+    L = _lib()
+    K, N = 4096, 256
+    M = (1 << 32) // (2 * K)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(device)
+    wh, wl = _split(W)
+    wi = _interleave(wh, wl)
+    img = torch.zeros(M + 1, 2 * K, dtype=torch.float16, device=device)        # 8.6 GB; rows outside the probes stay zero
+    probes = {0: 300, M // 2 - 7: 130, M - 256: 256}                            # first rows, a middle block, the last tile
+    blocks = {}
+    for r0, n in probes.items():
+        A = torch.randn(n, K, generator=g).to(device)
+        ah, al = _split(A)
+        img[r0:r0 + n] = _interleave(ah, al)
+        blocks[r0] = A
+    Cout = torch.empty(M, N, device=device)
+    try:
+        if kernel == "gemm256":
+            assert L.ovm_tune_set(b"op_gemm256", 1) == 0
+        rc = L.ovm_op_gemm(img.data_ptr(), img.data_ptr() + 64, 2 * K, wi.data_ptr(), wi.data_ptr() + 64, M, N, K, None, 0,
+                           Cout.data_ptr(), N, 3, _stream())
+        torch.cuda.synchronize()
+        assert rc == 0
+        for r0, A in blocks.items():
+            ref = (A.double() @ W.double().T).float()
+            assert_close(Cout[r0:r0 + A.shape[0]], ref, 3e-6, f"rows {r0}..")
+        assert float(Cout[400:M // 2 - 7].abs().max()) == 0.0 and float(Cout[M // 2 + 200:M - 256].abs().max()) == 0.0
+        rc = L.ovm_op_gemm(img.data_ptr(), img.data_ptr() + 64, 2 * K, wi.data_ptr(), wi.data_ptr() + 64, M + 1, N, K, None, 0,
+                           Cout.data_ptr(), N, 3, _stream())
+        assert rc == -5, "a launch whose last row lies beyond 2^32 elements must be refused (OVM_ERR_CAPACITY)"
+    finally:
+        L.ovm_tune_set(b"op_gemm256", 0)
+
+
+def test_create_refuses_offset_overflow(device):
+    """ovm_create checks max_batch x T x row length against the kernels' 32-bit offsets before it allocates anything."""
+    from common import build_cfg
+    from ovmono3d_amd.lib import OvmError
+    from ovmono3d_amd.native import Engine
+    from ovmono3d_amd.util.synth_weights import synth_state_dict
+    sd = synth_state_dict("vittest14", seed=1)
+    for mb, ok in ((64, True), (1 << 16, False)):
+        cfg = build_cfg("vittest14", 224, "f16x3", max_batch=mb, max_rois=4)
+        eng = Engine(cfg, device)
+        if ok:
+            eng.load_state_dict(sd)
+            eng.close()
+        else:
+            with pytest.raises(OvmError, match="32-bit"):
+                eng.load_state_dict(sd)

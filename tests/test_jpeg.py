@@ -105,13 +105,77 @@ def test_scope_and_errors():
     good = _jpeg(arr, quality=80)
     from ovmono3d_amd.lib import OvmError
     with pytest.raises(OvmError):
-        gpu_jpeg.entropy_decode(good[:len(good) // 2] )               # truncated entropy-coded segment: missing blocks decode from zeros,
-    with pytest.raises(OvmError):                                      # but a cut inside a marker segment is an error
+        gpu_jpeg.entropy_decode(good[:len(good) // 2])                # truncated entropy-coded segment (every cut: test_truncated_files_*)
+    with pytest.raises(OvmError):                                      # a cut inside a marker segment
         gpu_jpeg.jpeg_info(good[:30])
     with pytest.raises(OvmError):
         gpu_jpeg.jpeg_info(b"\x89PNG\r\n\x1a\n" + bytes(64))
     with pytest.raises(RuntimeError):
         gpu_jpeg.decode_jpeg(good, torch.device("cpu"))                # no CPU fallback of the reconstruction
+
+
+@pytest.mark.parametrize("kind", ["baseline_420", "restart_markers", "progressive", "grey_optimised"])
+def test_truncated_files_are_never_accepted(kind):
+    """A file cut anywhere must not decode to a partly grey image: Pillow - the reference's reader (dataset_mapper.py:38; cv2 links the same
+    libjpeg-turbo) - raises "image file is truncated" on such a file, so an evaluation over a damaged dataset fails there instead of scoring
+    garbage. The host decoder tracks when it starts CONSUMING the zero bits that stand in for missing data (BitReader::exhausted) and returns
+    OVM_ERR_INVALID. EVERY cut offset of four small files, with Pillow as the live judge: whatever Pillow refuses must be refused; where
+    Pillow still accepts (a cut behind the last entropy-coded byte), an accepted decode must equal Pillow's bit for bit."""
+    from oracle import jpeg_ref
+    from ovmono3d_amd.lib import OvmError
+    data = {"baseline_420": lambda: _jpeg(_scene(40, 56, 2), quality=80, subsampling=2),
+            "restart_markers": lambda: _jpeg(_scene(33, 47, 3), quality=70, subsampling=0, restart_marker_blocks=2),
+            "progressive": lambda: _jpeg(_scene(40, 56, 5), quality=70, subsampling=2, progressive=True),
+            "grey_optimised": lambda: _jpeg(_scene(24, 31, 4)[:, :, 0], quality=70, optimize=True)}[kind]()
+    assert np.array_equal(jpeg_ref.reconstruct(*(lambda c, i: (c.numpy(), i))(*gpu_jpeg.entropy_decode(data))), _pil(data))
+    refused_by_pillow = accepted_wrongly = accepted_both = 0
+    for cut in range(2, len(data)):
+        part = data[:cut]
+        try:
+            ref = _pil(part)
+        except Exception:
+            ref = None
+        try:
+            coef, info = gpu_jpeg.entropy_decode(part)
+            got = jpeg_ref.reconstruct(coef.numpy(), info)
+        except (OvmError, gpu_jpeg.UnsupportedJpeg):
+            got = None
+        if ref is None:
+            refused_by_pillow += 1
+            accepted_wrongly += got is not None
+        elif got is not None:
+            accepted_both += 1
+            assert np.array_equal(got, ref), f"cut at {cut}: accepted, but differs from Pillow"
+    assert refused_by_pillow > len(data) // 2
+    assert accepted_wrongly == 0, f"{accepted_wrongly} of {refused_by_pillow} truncations that Pillow refuses were decoded without an error"
+
+
+def test_exif_orientation_goes_to_the_host_reader_and_is_applied(tmp_path):
+    """Both readers of the reference apply the Exif Orientation tag (cv2.imread, demo/demo.py:52; detectron2 read_image ->
+    _apply_exif_orientation, dataset_mapper.py:38): a rotated phone JPEG reaches the model upright, with height and width swapped. The
+    device decoder leaves such files to the host reader (OVM_ERR_UNSUPPORTED -> UnsupportedJpeg), which transposes like Pillow's
+    ImageOps.exif_transpose; orientation 1 / no Exif stays on the device path."""
+    from PIL import ImageOps
+    from ovmono3d_amd.data.feeding import read_image
+    arr = _scene(40, 56, 7)
+    for orient in (1, 3, 6, 8):
+        exif = Image.Exif()
+        exif[0x0112] = orient
+        b = io.BytesIO()
+        Image.fromarray(arr).save(b, format="JPEG", quality=85, exif=exif.tobytes())
+        data = b.getvalue()
+        if orient == 1:
+            assert gpu_jpeg.jpeg_info(data).width == 56
+        else:
+            with pytest.raises(gpu_jpeg.UnsupportedJpeg):
+                gpu_jpeg.jpeg_info(data)
+        f = tmp_path / f"o{orient}.jpg"
+        f.write_bytes(data)
+        with Image.open(io.BytesIO(data)) as im:
+            want = np.asarray(ImageOps.exif_transpose(im).convert("RGB"))
+        got = read_image(str(f), "RGB")
+        assert got.shape == ((56, 40, 3) if orient in (6, 8) else (40, 56, 3)) and np.array_equal(got, want)
+        assert np.array_equal(read_image(str(f), "BGR"), want[:, :, ::-1])
 
 
 def test_corrupt_streams_are_refused_or_decoded_never_worse():
