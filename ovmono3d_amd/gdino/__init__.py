@@ -2,9 +2,9 @@
 ``ROIHeads3DGDINO`` calls (reference cubercnn/modeling/roi_heads/roi_heads_gdino.py:186,
 IDEA-Research/GroundingDINO @856dde2 - third-party, not in the reference tree).
 
-The network is sequenced on the host, module by module, in the structure of the published model; every
-arithmetic op is a libovm3d call (ovm_g_*: MFMA GEMM projections, LayerNorm, batched matmul, softmax,
-gathers, GroupNorm, multi-scale deformable sampling, ...). Weights use the parameter names of the
-Hugging Face port (``transformers`` ``GroundingDinoForObjectDetection``), which is also the independent
-CPU implementation the parity tests compare against.
+The whole network - BERT, Swin, fusion encoder, two-stage selection, decoder - is sequenced inside libovm3d
+(``ovm_gdino_create`` / ``ovm_gdino_forward``, csrc/gdino.hip); this package is its ctypes front end (``engine.py``), the
+architecture record (``config.py``) and the detector object the RoI head plugs in (``detector.py``: tokenisation, the
+upstream -> port parameter-name map). Weights use the parameter names of the Hugging Face port of the model, which is also the
+independent CPU implementation the parity tests compare against (tests/, never imported from here).
 """

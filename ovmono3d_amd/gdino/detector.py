@@ -13,8 +13,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from .. import lib as _lib
-from .model import GDinoConfig, GroundingDinoNative
-from .ops import Ops
+from .config import GDinoConfig
 
 
 class HashTokenizer:
@@ -38,7 +37,7 @@ class HashTokenizer:
 
 
 def convert_upstream_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-    """IDEA-Research/GroundingDINO checkpoint names -> the Hugging Face port's names used by ``GroundingDinoNative``.
+    """IDEA-Research/GroundingDINO checkpoint names -> the Hugging Face port's names the engine consumes.
     Written from the published module structures; it could not be checked against a real checkpoint offline."""
     out: Dict[str, torch.Tensor] = {}
     bb = "model.backbone.conv_encoder.model."
@@ -133,34 +132,23 @@ def convert_upstream_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.
 class NativeGroundingDino:
     """callable(image_u8_chw, caption) -> raw network outputs + token ids, as ROIHeads3DGDINO.forward expects.
 
-    Default (``engine=True``): the network runs inside libovm3d (``ovm_gdino_forward``, ``gdino/engine.py``): C++ sequencing,
-    fused kernels, one plan + HIP graph per (image size, caption), scratch owned by the plan. ``engine=False`` keeps the
-    round-1 path - generic ``ovm_g_*`` ops sequenced from Python (``gdino/model.py``), captured into a HIP graph the second
-    time an (image size, caption) pair is seen - as an independent cross-check of the engine; its process-global scratch can be
-    re-sized under a captured graph, so it should not be used with ``use_graphs`` on inputs of varying size."""
-
-    MAX_GRAPHS = 16
+    The network runs inside libovm3d (``ovm_gdino_forward``, ``gdino/engine.py``): C++ sequencing, fused kernels, one plan + HIP
+    graph per (image size, caption), scratch owned by the plan. There is no other route: without the HIP library the constructor
+    raises. (The round-1 form - generic ``ovm_g_*`` ops sequenced from Python - lives on under tests/pyref_gdino/ as an independent
+    cross-check of the engine; it is test infrastructure and not importable from the package.)"""
 
     def __init__(self, device: torch.device, state_dict: Dict[str, torch.Tensor], tokenizer, pixel_mean, pixel_std,
-                 cfg: GDinoConfig = GDinoConfig(), precision: int = 3, use_graphs: bool = True, engine: bool = True):
+                 cfg: GDinoConfig = GDinoConfig(), precision: int = 3, use_graphs: bool = True, max_plans: int = 16):
         if "model.text_projection.weight" not in state_dict:
             state_dict = convert_upstream_state_dict(state_dict)
         self.tok, self.mean, self.std = tokenizer, list(pixel_mean), list(pixel_std)
         self.use_graphs = use_graphs
-        self.engine = None
         self._tok_cache: Dict[str, tuple] = {}
-        if engine:
-            from .engine import GdinoEngine
-            # the reference hands GroundingDINO images[0][[2,1,0]]: the normalised, unpadded image with channels flipped (:146)
-            self.engine = GdinoEngine(device, state_dict, cfg, pixel_mean=self.mean, pixel_std=self.std, flip_channels=True,
-                                      precision=precision, use_graphs=use_graphs)
-            self.dev = device
-            return
-        self.ops = Ops(device, precision)
+        from .engine import GdinoEngine
+        # the reference hands GroundingDINO images[0][[2,1,0]]: the normalised, unpadded image with channels flipped (:146)
+        self.engine = GdinoEngine(device, state_dict, cfg, pixel_mean=self.mean, pixel_std=self.std, flip_channels=True,
+                                  precision=precision, use_graphs=use_graphs, max_plans=max_plans)
         self.dev = device
-        self.net = GroundingDinoNative(self.ops, state_dict, cfg)
-        self._graphs: Dict[tuple, tuple] = {}
-        self._seen: Dict[tuple, int] = {}
 
     def _tokens(self, caption: str):
         t = self._tok_cache.get(caption)
@@ -173,55 +161,8 @@ class NativeGroundingDino:
             t = self._tok_cache[caption] = (ids, phrase_ids, torch.tensor(ids, dtype=torch.int64))
         return t
 
-    def _run(self, im: torch.Tensor, ids_t: torch.Tensor):
-        d = _lib.OvmImage()
-        d.data = im.data_ptr()
-        d.height, d.width = int(im.shape[1]), int(im.shape[2])
-        d.stride_c, d.stride_h, d.stride_w = (int(s) for s in im.stride())
-        # the reference hands GroundingDINO images[0][[2,1,0]]: the normalised, unpadded image with channels flipped (:146)
-        x = self.ops.normalize_image(d, self.mean, self.std, flip=True)
-        return self.net.forward(x, d.height, d.width, ids_t)
-
     def __call__(self, image_u8_chw: torch.Tensor, caption: str) -> Dict:
         im = image_u8_chw.to(self.dev)
-        ids, phrase_ids, ids_t = self._tokens(caption)
-        if self.engine is not None:
-            logits, boxes = self.engine.forward(im, ids)
-            return {"pred_logits": logits, "pred_boxes": boxes, "input_ids": ids, "phrase_ids": phrase_ids}
-        key = (tuple(im.shape), tuple(ids))
-        entry = self._graphs.get(key) if self.use_graphs else None
-        if entry is None and self.use_graphs:
-            self._seen[key] = self._seen.get(key, 0) + 1
-            if self._seen[key] >= 2:                                       # first sight ran eagerly: scratch buffers are sized
-                try:
-                    entry = self._capture(key, im, ids_t)
-                except RuntimeError as e:                                  # capture refused (driver / allocator state): stay eager, same results
-                    import warnings
-                    warnings.warn(f"HIP graph capture of the GroundingDINO forward failed ({e}); continuing without graphs")
-                    self.use_graphs = False
-                    torch.cuda.synchronize(self.ops.dev)
-        if entry is None:
-            logits, boxes = self._run(im, ids_t)
-        else:
-            graph, static_im, logits, boxes = entry
-            static_im.copy_(im)
-            graph.replay()
+        ids, phrase_ids, _ = self._tokens(caption)
+        logits, boxes = self.engine.forward(im, ids)
         return {"pred_logits": logits, "pred_boxes": boxes, "input_ids": ids, "phrase_ids": phrase_ids}
-
-    def _capture(self, key, im, ids_t):
-        dev = self.ops.dev
-        static_im = torch.empty(tuple(im.shape), dtype=im.dtype, device=dev)
-        static_im.copy_(im)
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):                                      # warm-up on the capture-side stream
-            self._run(static_im, ids_t)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            logits, boxes = self._run(static_im, ids_t)
-        if len(self._graphs) >= self.MAX_GRAPHS:
-            self._graphs.pop(next(iter(self._graphs)))
-        entry = self._graphs[key] = (graph, static_im, logits, boxes)
-        return entry

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from .. import lib as _lib
-from .model import GDinoConfig
+from .config import GDinoConfig
 
 
 class GdinoEngine:

@@ -43,7 +43,7 @@ class ROIHeads3DGDINO(ROIHeads3D):
         cfg = self._gdino_cfg
         path = cfg.MODEL.AMD.GDINO_WEIGHTS
         if path.startswith("synthetic://"):
-            from ...util.synth_gdino import synth_gdino_state_dict
+            from ...util.synth_gdino_weights import synth_gdino_state_dict
             seed = int(path.split("seed=")[1]) if "seed=" in path else 0
             sd, tok = synth_gdino_state_dict(seed), HashTokenizer()
         else:

@@ -36,7 +36,7 @@ def upstream_position_ids():
     """(2) HF numbers the text positions its own way (the '.' delimiters get position 0); upstream - which the native path
     follows - numbers them 0..len inside each phrase, delimiter included. Inside this context HF uses upstream's ids."""
     import transformers.models.grounding_dino.modeling_grounding_dino as mgd
-    from ovmono3d_amd.gdino.bert import masks_and_position_ids
+    from pyref_gdino.bert import masks_and_position_ids
     orig = mgd.generate_masks_with_special_tokens_and_transfer_map
     mgd.generate_masks_with_special_tokens_and_transfer_map = \
         lambda ids: (orig(ids)[0], masks_and_position_ids(ids[0].cpu())[1][None].to(ids.device))

@@ -7,6 +7,9 @@ This is the network ``ROIHeads3DGDINO`` calls at reference cubercnn/modeling/roi
 configuration of reference configs/GroundingDINO_SwinB_cfg.py (IDEA-Research/GroundingDINO @856dde2; source not in the
 reference tree). Module structure and parameter names follow the Hugging Face port (``GroundingDinoForObjectDetection``),
 the independent CPU implementation the parity test compares against. The host sequences ops; all arithmetic is in libovm3d.
+
+TEST INFRASTRUCTURE (tests/pyref_gdino): the round-1 Python-sequenced form of the detector, kept as an independent cross-check of the
+C++ engine behind ovm_gdino_forward (ovmono3d_amd/gdino/engine.py). Not part of the product package; nothing in ovmono3d_amd imports it.
 Constant tables that depend only on tensor shapes (sine position embeddings, reference grids, proposal grids, index maps)
 are built once per input size on the host.
 """
@@ -19,30 +22,12 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
+from ovmono3d_amd.gdino.config import GDinoConfig  # noqa: F401
+
 from . import ops as O
 from .bert import BertEncoder, masks_and_position_ids
 from .ops import ACT_RELU, Ops
 from .swin import SwinBackbone
-
-
-@dataclass
-class GDinoConfig:
-    d_model: int = 256
-    enc_layers: int = 6
-    dec_layers: int = 6
-    heads: int = 8
-    ffn_dim: int = 2048
-    n_levels: int = 4
-    n_points: int = 4
-    num_queries: int = 900
-    max_text_len: int = 256
-    pe_temperature: float = 20.0
-    eps: float = 1e-5
-    bert_heads: int = 12
-    swin_embed: int = 128
-    swin_depths: Sequence[int] = (2, 2, 18, 2)
-    swin_heads: Sequence[int] = (4, 8, 16, 32)
-    swin_window: int = 12
 
 
 def _sine_pos(h: int, w: int, d_half: int, temperature: float) -> torch.Tensor:

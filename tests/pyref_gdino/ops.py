@@ -7,7 +7,7 @@ from typing import Optional, Sequence
 
 import torch
 
-from .. import lib as _lib
+from ovmono3d_amd import lib as _lib
 
 ADD, MUL, RELU, GELU, SIGMOID, CLAMP, AXPY, INVSIG, COPY, MASKFILL = range(10)     # ovm_g_eltwise op codes
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2                                               # ovm_g_linear activation codes

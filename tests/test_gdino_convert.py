@@ -113,3 +113,34 @@ def test_upstream_names_convert_back_to_every_native_key():
     for k, v in back.items():
         assert k in sd, k
         assert torch.equal(v, sd[k]), k
+
+
+def test_synthetic_gdino_weights_cover_the_hf_ports_parameter_tree():
+    """`synthetic://gdino?seed=N` (ovmono3d_amd/util/synth_gdino_weights.py) builds random-init GroundingDINO weights from the
+    architecture record alone - the product package imports no model library. Its key set and shapes must be exactly the float
+    parameters of the Hugging Face port (the naming ovm_gdino_create consumes), at the full Swin-B / BERT-base / 900-query size."""
+    from synth_gdino import synth_gdino_model
+    from ovmono3d_amd.util.synth_gdino_weights import synth_gdino_state_dict
+    _, ref = synth_gdino_model(0)
+    mine = synth_gdino_state_dict(3)
+    want = {k: tuple(v.shape) for k, v in ref.items() if v.dtype.is_floating_point}
+    got = {k: tuple(v.shape) for k, v in mine.items()}
+    assert got == want
+    a, b = synth_gdino_state_dict(3), synth_gdino_state_dict(4)
+    assert all(torch.equal(mine[k], a[k]) for k in mine) and not torch.equal(a["model.level_embed"], b["model.level_embed"])
+    assert mine["bbox_embed.5.layers.2.weight"] is mine["model.decoder.bbox_embed.0.layers.2.weight"]      # shared box MLP under every alias
+
+
+def test_product_package_does_not_import_checker_libraries():
+    """The product package must not import the checker libraries (transformers / the oracle / tests): static scan of its sources."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ovmono3d_amd")
+    bad = []
+    for dp, _, fs in os.walk(root):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                for m in re.finditer(r"^\s*(?:from|import)\s+(transformers|oracle|pyref_gdino|synth_gdino|hf_gdino_patches|parity|common)\b", src, re.M):
+                    bad.append((os.path.relpath(os.path.join(dp, f), root), m.group(0).strip()))
+    assert not bad, bad

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _ops(device, precision=3):
-    from ovmono3d_amd.gdino.ops import Ops
+    from pyref_gdino.ops import Ops
     return Ops(device, precision)
 
 
@@ -115,7 +115,7 @@ def test_msdeform_and_sine_embed_match_hf(device):
 def test_bert_text_encoder_matches_hf(device):
     from transformers import BertConfig, BertModel
     from transformers.models.grounding_dino.modeling_grounding_dino import generate_masks_with_special_tokens_and_transfer_map
-    from ovmono3d_amd.gdino.bert import BertEncoder, masks_and_position_ids
+    from pyref_gdino.bert import BertEncoder, masks_and_position_ids
     torch.manual_seed(0)
     cfg = BertConfig(vocab_size=2000, hidden_size=768, num_hidden_layers=3, num_attention_heads=12, intermediate_size=3072,
                      max_position_embeddings=512, attn_implementation="eager")
@@ -146,7 +146,7 @@ def test_bert_text_encoder_matches_hf(device):
 
 def test_swin_backbone_matches_hf(device):
     from transformers import SwinBackbone as HFSwin, SwinConfig
-    from ovmono3d_amd.gdino.swin import SwinBackbone
+    from pyref_gdino.swin import SwinBackbone
     torch.manual_seed(0)
     cfg = SwinConfig(image_size=384, patch_size=4, embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], window_size=12,
                      out_indices=[2, 3, 4], layer_norm_eps=1e-5)
@@ -202,7 +202,7 @@ from hf_gdino_patches import patch_hf_to_upstream as _patch_hf_to_upstream, upst
 
 def test_full_gdino_network_matches_hf(device):
     from transformers.models.grounding_dino.modeling_grounding_dino import generate_masks_with_special_tokens_and_transfer_map
-    from ovmono3d_amd.gdino.model import GDinoConfig, GroundingDinoNative
+    from pyref_gdino.model import GDinoConfig, GroundingDinoNative
     hf, cfg = _small_hf_gdino()
     H, W = 96, 132
     g = torch.Generator().manual_seed(2)
@@ -234,8 +234,8 @@ def test_full_size_gdino_swinb_matches_hf(device):
     import time
     from transformers.models.grounding_dino.modeling_grounding_dino import generate_masks_with_special_tokens_and_transfer_map
     from ovmono3d_amd.gdino.detector import HashTokenizer
-    from ovmono3d_amd.gdino.model import GDinoConfig, GroundingDinoNative
-    from ovmono3d_amd.util.synth_gdino import synth_gdino_model
+    from pyref_gdino.model import GDinoConfig, GroundingDinoNative
+    from synth_gdino import synth_gdino_model
     hf, sd = synth_gdino_model(5)
     _patch_hf_to_upstream(hf)
     hf = hf.to(device)
@@ -273,11 +273,12 @@ def test_full_size_gdino_swinb_matches_hf(device):
 
 
 def test_detector_graph_replay_matches_eager(device):
-    """The Python-sequenced cross-check path (engine=False) captures its forward into a HIP graph on the second sight of an
+    """The Python-sequenced cross-check path (tests/pyref_gdino) captures its forward into a HIP graph on the second sight of an
     (image size, caption) pair; the replay on new pixels must equal the eager forward on those pixels bit for bit. (The product
     path is the C++ engine: tests/test_gpu_gdino_engine.py.)"""
-    from ovmono3d_amd.gdino.detector import HashTokenizer, NativeGroundingDino
-    from ovmono3d_amd.gdino.model import GDinoConfig
+    from ovmono3d_amd.gdino.detector import HashTokenizer
+    from ovmono3d_amd.gdino.config import GDinoConfig
+    from pyref_gdino.detector import PySequencedGroundingDino
     hf, cfg = _small_hf_gdino()
     ncfg = GDinoConfig(d_model=64, enc_layers=2, dec_layers=2, heads=4, ffn_dim=128, num_queries=30, bert_heads=2, swin_embed=32,
                        swin_depths=(2, 2, 2, 2), swin_heads=(1, 2, 4, 8), swin_window=12)
@@ -287,8 +288,8 @@ def test_detector_graph_replay_matches_eager(device):
     class Tok(HashTokenizer):
         def _id(self, w):
             return super()._id(w) % 1900 + 50 if w not in (".", "?") else super()._id(w)
-    eager = NativeGroundingDino(device, sd, Tok(), mean, std, cfg=ncfg, use_graphs=False, engine=False)
-    graphed = NativeGroundingDino(device, sd, Tok(), mean, std, cfg=ncfg, use_graphs=True, engine=False)
+    eager = PySequencedGroundingDino(device, sd, Tok(), mean, std, cfg=ncfg, use_graphs=False)
+    graphed = PySequencedGroundingDino(device, sd, Tok(), mean, std, cfg=ncfg, use_graphs=True)
     g = torch.Generator().manual_seed(3)
     caption = "chair . dining table ."
     for i in range(4):
@@ -308,9 +309,9 @@ def test_roiheads3dgdino_end_to_end_vs_hf_and_oracle(device):
     from common import build_cfg, oracle_params, synth_inputs
     from oracle import gdino_glue as og
     from oracle.pipeline import inference
-    from ovmono3d_amd.gdino.bert import masks_and_position_ids
+    from pyref_gdino.bert import masks_and_position_ids
     from ovmono3d_amd.gdino.detector import HashTokenizer, NativeGroundingDino
-    from ovmono3d_amd.gdino.model import GDinoConfig
+    from ovmono3d_amd.gdino.config import GDinoConfig
     from ovmono3d_amd.modeling import build_model
     from ovmono3d_amd.util.synth_weights import synth_state_dict
     hf, _ = _small_hf_gdino()
@@ -374,7 +375,7 @@ def test_headline_config_on_coco_example_vs_hf_and_oracle(device):
     from ovmono3d_amd.data import ResizeShortestEdge, read_image
     from ovmono3d_amd.gdino.detector import HashTokenizer, NativeGroundingDino
     from ovmono3d_amd.modeling import build_model
-    from ovmono3d_amd.util.synth_gdino import synth_gdino_model
+    from synth_gdino import synth_gdino_model
     from ovmono3d_amd.util.synth_weights import synth_state_dict
     torch.set_num_threads(16)
     cats = ["bicycle", "cat"]                                                    # labels.json entry of this image

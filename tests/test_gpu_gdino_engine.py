@@ -25,7 +25,7 @@ def _normalised(img_u8):
 
 def _engine(device, sd, cfg_kwargs, **kw):
     from ovmono3d_amd.gdino.engine import GdinoEngine
-    from ovmono3d_amd.gdino.model import GDinoConfig
+    from ovmono3d_amd.gdino.config import GDinoConfig
     return GdinoEngine(device, sd, GDinoConfig(**cfg_kwargs), pixel_mean=MEAN, pixel_std=STD, flip_channels=True, **kw)
 
 
@@ -56,8 +56,8 @@ def test_engine_matches_hf_small(device):
 
 def test_engine_matches_python_sequenced_path_small(device):
     """Same weights through the round-1 Python-sequenced generic-op path (itself checked against HF): intermediate taps agree."""
-    from ovmono3d_amd.gdino.model import GDinoConfig, GroundingDinoNative
-    from ovmono3d_amd.gdino.ops import Ops
+    from pyref_gdino.model import GDinoConfig, GroundingDinoNative
+    from pyref_gdino.ops import Ops
     hf, _ = _small_hf_gdino()
     H, W = 100, 130                                             # not multiples of the patch / window sizes
     g = torch.Generator().manual_seed(5)
@@ -132,7 +132,7 @@ def test_engine_full_size_swinb_matches_hf(device):
     random weights; HF runs in fp32 on the same GPU. Also prints the engine's kernel launches per forward and its time."""
     from transformers.models.grounding_dino.modeling_grounding_dino import generate_masks_with_special_tokens_and_transfer_map
     from ovmono3d_amd.gdino.detector import HashTokenizer
-    from ovmono3d_amd.util.synth_gdino import synth_gdino_model
+    from synth_gdino import synth_gdino_model
     hf, sd = synth_gdino_model(5)
     patch_hf_to_upstream(hf)
     hf = hf.to(device)
@@ -179,7 +179,7 @@ def test_ovm_infer_one_call_equals_staged_path(device, tower):
     (ROIHeads3DGDINO.prefetch / forward): identical records. Replaces reference rcnn3d.py:79-117 with category_list."""
     from common import build_cfg, build_clip_cfg, synth_inputs
     from ovmono3d_amd.gdino.detector import HashTokenizer, NativeGroundingDino
-    from ovmono3d_amd.gdino.model import GDinoConfig
+    from ovmono3d_amd.gdino.config import GDinoConfig
     from ovmono3d_amd.modeling import build_model
     from ovmono3d_amd.util.synth_weights import synth_state_dict
     hf, _ = _small_hf_gdino()

@@ -398,8 +398,11 @@ def _batch8_every_image(device, cfg, sd_seed, shapes, orig_scale, n_boxes, seed,
     """A real batch of 8 images per GPU (BASELINE configs[2..4]: 16 / 2, 32 / 4, 64 / 8) of >= 3 distinct network shapes through
     one call, every image checked (reference omni3d_evaluation.py:652-667 feeds the model whole batches):
       * images 0 and 7 against the CPU oracle: ids exact, every float field within 1e-3;
-      * every image against ITS OWN batch-1 run on the HIP path: ids exact, floats within 1e-6 (scale-relative; a batch changes
-        tile / split-K assignment, i.e. fp32 summation order, never the arithmetic) - the batch-1 route is oracle-anchored by
+      * every image against ITS OWN batch-1 run on the HIP path: ids exact, floats within 1e-5 (scale-relative). A batch never changes
+        the arithmetic, only fp32 summation order: whether a thin GEMM grid is split along K (the pyramid's convolutions: <= 96 tiles at
+        B = 1, more at B = 8), and which rows of the token matrix fall into the leftover-row dot-product workgroups (M = B x 4097 =
+        whole tiles + 1 row at B = 1, + 8 rows at B = 8) - ~1e-7 on the features, amplified to 2-4e-6 on pred_pose by the
+        random-init 6-D head (measured; every field is reported below) - the batch-1 route is oracle-anchored by
         test_oracle2d_vitl_canvas896_headline_size / test_clip_vitb16_canvas1024_config4_size and by images 0 and 7 here."""
     from oracle.pipeline import inference
     model, sd = _build(cfg, seed=sd_seed)
@@ -407,7 +410,7 @@ def _batch8_every_image(device, cfg, sd_seed, shapes, orig_scale, n_boxes, seed,
     assert len({tuple(d["image"].shape[1:]) for d in inputs}) >= 3
     out = model(inputs)
     assert len(out) == 8
-    worst = 0.0
+    worst = {f: 0.0 for f in FIELDS}
     for i in range(8):
         solo = model([inputs[i]])[0]["instances"]
         inst = out[i]["instances"]
@@ -416,8 +419,8 @@ def _batch8_every_image(device, cfg, sd_seed, shapes, orig_scale, n_boxes, seed,
         for f in FIELDS:
             a, b = inst.get(f), solo.get(f)
             a, b = (a.tensor if hasattr(a, "tensor") else a), (b.tensor if hasattr(b, "tensor") else b)
-            worst = max(worst, assert_close(a, b, 1e-6, f"image {i} {f} (batch 8 vs batch 1)"))
-    print(f"{label}: batch 8 vs batch 1 on the HIP path, worst field error over 8 images {worst:.2e}")
+            worst[f] = max(worst[f], assert_close(a, b, 1e-5, f"image {i} {f} (batch 8 vs batch 1)"))
+    print(f"{label}: batch 8 vs batch 1 on the HIP path, worst error over 8 images: " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
     torch.set_num_threads(16)
     ref = inference(sd, [inputs[0], inputs[7]], oracle_params(cfg))
     _compare([out[0], out[7]], ref)

@@ -37,7 +37,7 @@ def build_detector(cfg, device):
     from ovmono3d_amd.modeling.roi_heads.gdino_glue import WordPieceTokenizer
     path = cfg.MODEL.AMD.GDINO_WEIGHTS
     if path.startswith("synthetic://"):
-        from ovmono3d_amd.util.synth_gdino import synth_gdino_state_dict
+        from ovmono3d_amd.util.synth_gdino_weights import synth_gdino_state_dict
         sd, tok = synth_gdino_state_dict(int(path.split("seed=")[1]) if "seed=" in path else 0), HashTokenizer()
     else:
         sd, tok = load_state_dict_file(path), WordPieceTokenizer(cfg.MODEL.AMD.BERT_VOCAB)
