@@ -328,18 +328,21 @@ def main():
         except Exception as e:
             alt_canvas = {"mode": "tight", "error": repr(e)[:200]}
 
-    # ---- a dataset does not come in one shape: 32 synthetic images of mixed network resolutions through the same model
-    # (ResizeShortestEdge(532, 896) outputs of common aspect ratios), one image per step as the evaluation loop feeds them.
-    # The detector captures one HIP graph per padded shape on first sight (plan cache), so pass 1 pays the captures and
-    # pass 2 is the steady state. Reported next to the fixed-shape headline, never as `value`.
+    # ---- a dataset does not come in one shape: 90 synthetic images of 45 distinct network resolutions through the same model
+    # (what ResizeShortestEdge(532, 896) emits for aspect ratios 0.59 .. 1.68), one image per step as the evaluation loop feeds
+    # them. The detector builds one plan + HIP graph per padded shape on first sight (plan cache: LRU bounded by bytes), so pass 1
+    # pays the captures and the later passes are the steady state. The same images GROUPED by shape (every plan switch removed) are
+    # timed beside the mixed order: their ratio is what switching plans costs. Larger images carry more detector work than the
+    # 532 x 532 headline, so neither figure is comparable with `value`; reported next to it, never as `value`.
     mixed = None
     if not args.no_alt and world == 1 and args.canvas == 896 and args.net_res == 532:
         try:
-            shapes = [(532, 532), (532, 709), (532, 798), (532, 896), (709, 532), (896, 532), (532, 665), (504, 896)]
+            shapes = [(532, w) for w in range(532, 897, 16)] + [(h, 532) for h in range(548, 897, 16)]
             g = torch.Generator().manual_seed(77)
+            order = torch.randperm(2 * len(shapes), generator=g).tolist()
             mixed_inputs = []
-            for i in range(32):
-                hh, ww = shapes[int(torch.randint(0, len(shapes), (1,), generator=g))]
+            for i in order:
+                hh, ww = shapes[i % len(shapes)]
                 d = {"image": torch.randint(0, 256, (3, hh, ww), dtype=torch.uint8, generator=g).to(dev), "height": hh, "width": ww,
                      "K": [[2.0 * hh, 0.0, ww / 2], [0.0, 2.0 * hh, hh / 2], [0.0, 0.0, 1.0]], "image_id": i}
                 if use_gdino:
@@ -347,18 +350,29 @@ def main():
                 elif not use_rpn:
                     d["oracle2D"] = host_inputs[0]["oracle2D"]
                 mixed_inputs.append(d)
-            passes = []
-            for _ in range(3):
+            grouped = sorted(mixed_inputs, key=lambda d: tuple(d["image"].shape[1:]))
+
+            def one_pass(seq):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                for d in mixed_inputs:
+                for d in seq:
                     model([d])
                 torch.cuda.synchronize()
-                passes.append(time.perf_counter() - t0)
-            mixed = {"images": 32, "distinct_shapes": len({tuple(d["image"].shape[1:]) for d in mixed_inputs}),
-                     "images_per_sec_first_pass": round(32 / passes[0], 2), "images_per_sec": round(32 / min(passes[1:]), 2),
-                     "note": "network resolutions 532..896 on the 896 canvas, one image per step in dataset order; the first pass "
-                             "includes one graph capture per new shape"}
+                return time.perf_counter() - t0
+            n = len(mixed_inputs)
+            first = one_pass(mixed_inputs)
+            t_mixed = min(one_pass(mixed_inputs) for _ in range(2))
+            t_grouped = min(one_pass(grouped) for _ in range(2))
+            mixed = {"images": n, "distinct_shapes": len({tuple(d["image"].shape[1:]) for d in mixed_inputs}),
+                     "images_per_sec_first_pass": round(n / first, 2), "images_per_sec": round(n / t_mixed, 2),
+                     "images_per_sec_grouped_by_shape": round(n / t_grouped, 2), "mixed_over_grouped": round(t_grouped / t_mixed, 4),
+                     "note": "network resolutions 532 x 532 .. 532 x 896 / 896 x 532 on the 896 canvas, one image per step; the first pass "
+                             "includes one plan + graph capture per new shape; mixed_over_grouped = the steady-state rate in shuffled "
+                             "dataset order relative to the same images grouped by shape (1.0 = switching plans is free)"}
+            if use_gdino:
+                eng = model.roi_heads.detector.engine
+                mixed["plans_held"] = int(eng.debug_scalar("plans"))
+                mixed["plan_cache_mb"] = round(eng.debug_scalar("plan_bytes") / 2 ** 20, 1)
         except Exception as e:                                   # the extra measurement must never break the contract line
             mixed = {"error": repr(e)[:300]}
 
@@ -456,7 +470,7 @@ def main():
                 ok_all &= bool(parity_ok(e2e, 1e-3))
         if B > 1:
             from parity import FIELDS as _PF
-            worst, ids_ok, counts_ok = 0.0, True, True
+            worst, worst_pose, ids_ok, counts_ok = 0.0, 0.0, True, True
             with torch.no_grad():
                 for i in range(B):
                     solo = model([inputs_dev[i]])[0]["instances"]
@@ -470,16 +484,22 @@ def main():
                     for f in _PF:
                         a_, b_ = inst.get(f), solo.get(f)
                         a_, b_ = (a_.tensor if hasattr(a_, "tensor") else a_).double(), (b_.tensor if hasattr(b_, "tensor") else b_).double()
-                        worst = max(worst, float((a_ - b_).abs().max() / b_.abs().max().clamp_min(1e-30)))
-            parity["batch_vs_batch1"] = {"images": B, "same_counts": counts_ok, "class_ids_exact": ids_ok, "worst_rel_err": worst}
-            ok_all &= bool(counts_ok and ids_ok and worst <= 1e-5)
+                        e_ = float((a_ - b_).abs().max() / b_.abs().max().clamp_min(1e-30))
+                        if f == "pred_pose":
+                            worst_pose = max(worst_pose, e_)
+                        else:
+                            worst = max(worst, e_)
+            parity["batch_vs_batch1"] = {"images": B, "same_counts": counts_ok, "class_ids_exact": ids_ok, "worst_rel_err": worst,
+                                         "worst_rel_err_pose": worst_pose}
+            ok_all &= bool(counts_ok and ids_ok and worst <= 1e-5 and worst_pose <= 1e-4)
         parity["ok_1e-3"] = bool(ok_all)
         parity["criteria"] = ("max_rel_err = max|a-b| / max|b| per field; max_elem_rel_err = max_i |a_i-b_i| / max(|b_i|, floor) with the floors of "
                               "tests/parity.py:ELEM_FLOOR. Gate: class ids exact, every float field <= 1e-3 (max_rel_err)"
                               + ("; behind the proposal stage: same_boxes strict (identity pairing), end_to_end with <= 1 % of the detections "
-                                 "flipped by discrete near-ties and pred_pose held to the angle a 1e-3-relative perturbation of the head's raw "
-                                 "6-D output causes at that detection's own conditioning (pose.max_geodesic_over_1e-3xamp <= 1)" if proposal_stage else "")
-                              + ("; batch_vs_batch1: every image of the batch equals its own batch-1 run within 1e-5, ids exact" if B > 1 else ""))
+                                 "flipped by discrete near-ties, pred_pose <= 1e-3 on every detection whose 6-D -> R map is well conditioned "
+                                 "(amplification <= 10) and, for near-degenerate Gram-Schmidt inputs, held to the angle a 1e-3-relative "
+                                 "perturbation of the raw 6-D output causes at that conditioning (pose.* fields; tests/parity.py)" if proposal_stage else "")
+                              + ("; batch_vs_batch1: every image of the batch equals its own batch-1 run within 1e-5 (pred_pose, which carries the 6-D head's conditioning, 1e-4), ids exact" if B > 1 else ""))
         parity["oracle"] = ("oracle/ restatement" + (" + Hugging Face GroundingDINO port" if use_gdino else "")
                             + "; unpinned vs the reference itself (no reference fixtures exist, DESIGN.md 5)")
 

@@ -273,7 +273,11 @@ typedef struct OvmGdinoConfig {
   int32_t flip_channels;                                          /* 1: the reference's images[0][[2,1,0]] (roi_heads_gdino.py:146) */
   int32_t precision;                                              /* 1 = fp16 operands, 3 = split fp16 (default) */
   int32_t use_graphs;                                             /* capture each plan's forward into a HIP graph */
-  int32_t max_plans;                                              /* plans kept (LRU); 0 = 16 */
+  int32_t max_plans;                                              /* plans kept (LRU); 0 = 128 */
+  int32_t plan_budget_mb;                                         /* device memory the kept plans may hold together (arenas, tables,
+                                                                     split-K workspaces), MiB; least recently used plans go first;
+                                                                     0 = 32768. A dataset has more aspect ratios than any fixed
+                                                                     count: the bound that matters is bytes */
 } OvmGdinoConfig;
 int ovm_gdino_create(const OvmGdinoConfig* cfg, const OvmTensor* weights, int32_t n_weights, int32_t device, OvmGdino** out);
 int ovm_gdino_destroy(OvmGdino* g);

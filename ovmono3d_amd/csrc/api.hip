@@ -330,7 +330,10 @@ int gemm(OvmHandle* h, const GemmParams& p, int epi, int amode, hipStream_t s, i
   ProfScope ps(h, cat, s);
   // the large block contractions (qkv, fc1: >= 2048 rows and >= 3072 columns -> at least 192 tiles of 256 x 256) go to the
   // two-wave-group 256 x 256 kernel; everything else keeps the 128 x 128 kernels
-  if (g_use_gemm256 && amode == A_ROWMAJOR && p.M >= 2048 && p.N >= 3072 && gemm256_supported(p, h->npass))
+  // (at batch >= 4 the N = D contractions - proj, fc2 - reach that tile count too: 128 x 128 tiles fetch twice the operand bytes
+  // per MFMA from L2, which is what bounds them at batch 1, where only 128-wide tiles fill the chip)
+  if (g_use_gemm256 && amode == A_ROWMAJOR && gemm256_supported(p, h->npass) &&
+      (long)((p.M + 255) / 256) * (p.N / 256) >= 192 && (epi == EPI_STORE || epi == EPI_RESID || epi == EPI_GELU || epi == EPI_QKV))
     return launch_gemm256(p, epi, 1, s);
   return launch_gemm(p, h->npass, epi, amode, s);
 }

@@ -13,6 +13,7 @@
 //
 // NPASS=3 uses split operands (hi + lo) for both products, three MFMAs per product into the same accumulator.
 #include "kernels.hpp"
+#include "attn_tail.hpp"
 #include <type_traits>
 
 namespace ovm {
@@ -43,9 +44,6 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_n() {
 }
 
 constexpr float kPShift = 14.0f;       // log2 of the scale the main kernel carries its probabilities at
-
-template <int NPASS>
-__device__ __forceinline__ void attn_tail_body(const AttnParams& p, int tb, char* smem);
 
 // Software-pipelined over key tiles inside each wave: iteration t issues the S^T MFMAs of tile t+1, the
 // softmax VALU work of tile t and the PV MFMAs of tile t as one basic block, so matrix and vector pipes
@@ -589,100 +587,6 @@ __global__ __launch_bounds__(512, 1) void attn_pp_kernel(const AttnParams p) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Tail query rows. T = 4097 leaves ONE query past 32 blocks of 128; as a 33rd block per head it would
-// add a second, nearly empty round of workgroups. Up to 8 leftover queries per (batch, head) are handled by
-// extra workgroups of the same launch instead: scores and probabilities in LDS, fp32 FMAs on the
-// reconstructed (hi + lo) operands, all global reads coalesced along the contiguous axis.
-// ---------------------------------------------------------------------------------------------
-template <int NPASS>
-__device__ __forceinline__ void attn_tail_body(const AttnParams& p, int tb, char* smem) {
-  float* sc = (float*)smem;                       // [Tpad] scores -> probabilities, in V^T's permuted token order
-  float* red = sc + p.Tpad;                       // [16]: per-wave maxima, per-wave sums
-  const int nw = blockDim.x >> 6;                 // 4 or 8 waves
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ntail = p.T - p.Tq;
-  const int bh = tb / ntail, q = p.Tq + (tb - bh * ntail);
-  const int b = bh / p.heads, head = bh - b * p.heads;
-  const int T = p.T, Tpad = p.Tpad;
-  const size_t qk_base = (size_t)bh * T * 64;
-  const size_t v_base = (size_t)bh * 64 * Tpad;
-  // lane l of a wave holds q[8*(l&7) .. +8): 8 lanes cover one key row (128 B contiguous), 8 keys per wave pass
-  float qv[8];
-  {
-    const half8 qh = *(const half8*)(p.Qhi + qk_base + (size_t)q * 64 + 8 * (lane & 7));
-#pragma unroll
-    for (int j = 0; j < 8; ++j) qv[j] = (float)qh[j];
-    if (NPASS == 3) {
-      const half8 ql = *(const half8*)(p.Qlo + qk_base + (size_t)q * 64 + 8 * (lane & 7));
-#pragma unroll
-      for (int j = 0; j < 8; ++j) qv[j] += (float)ql[j];
-    }
-  }
-  float mx = -1e30f;
-  for (int t0 = wave * 8; t0 < Tpad; t0 += 8 * nw) {
-    const int t = t0 + (lane >> 3);
-    float s = 0.f;
-    if (t < T) {
-      const half8 kh = *(const half8*)(p.Khi + qk_base + (size_t)t * 64 + 8 * (lane & 7));
-      half8 kl;
-      if (NPASS == 3) kl = *(const half8*)(p.Klo + qk_base + (size_t)t * 64 + 8 * (lane & 7));
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float kv = (float)kh[j];
-        if (NPASS == 3) kv += (float)kl[j];
-        s = fmaf(qv[j], kv, s);
-      }
-    }
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-    if (t >= T) s = -1e30f;
-    if ((lane & 7) == 0) {
-      const int tp = (t & ~15) | (t & 3) | ((t & 4) << 1) | ((t & 8) >> 1);
-      sc[tp] = s;
-    }
-    mx = fmaxf(mx, s);
-  }
-  mx = wave_max(mx);
-  if (lane == 0) red[wave] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  if (nw == 8) mx = fmaxf(mx, fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
-  float sum = 0.f;
-  for (int t = tid; t < Tpad; t += blockDim.x) {
-    const float e = __builtin_amdgcn_exp2f(sc[t] - mx);   // scores are in log2 units; masked slots hold -1e30 -> 0
-    sc[t] = e;
-    sum += e;
-  }
-  sum = wave_sum(sum);
-  if (lane == 0) red[8 + wave] = sum;
-  __syncthreads();
-  float tot = red[8] + red[9] + red[10] + red[11];
-  if (nw == 8) tot += red[12] + red[13] + red[14] + red[15];
-  const float inv = 1.0f / tot;
-  // O[d] = sum_t p[t] V^T[d][t]: wave w owns d = w, w + nw, ...; lanes run along the token axis (coalesced)
-  for (int d = wave; d < 64; d += nw) {
-    float o = 0.f;
-    for (int j = lane * 8; j < Tpad; j += 512) {
-      const half8 h8 = *(const half8*)(p.Vhi + v_base + (size_t)d * Tpad + j);
-      half8 l8;
-      if (NPASS == 3) l8 = *(const half8*)(p.Vlo + v_base + (size_t)d * Tpad + j);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float v = (float)h8[e];
-        if (NPASS == 3) v += (float)l8[e];
-        o = fmaf(sc[j + e], v, o);
-      }
-    }
-    o = wave_sum(o);
-    if (lane == 0) {
-      half_t hh, ll; split_f16(o * inv, hh, ll);
-      const size_t oo = ((size_t)b * T + q) * p.ldo + (p.o_il ? il_col(head * 64 + d) : head * 64 + d);
-      p.Ohi[oo] = hh;
-      if (p.Olo) p.Olo[oo] = ll;
-    }
-  }
-}
-
 static int g_attn_tail = 1;
 void attn_set_tail_rows(int on) { g_attn_tail = on; }
 static int g_attn_lds_pad = 0;      // experiment: extra dynamic LDS per workgroup (lowers workgroups per CU)
@@ -694,6 +598,12 @@ void attn_set_prio(int v) { g_attn_prio = v; }
 static int g_attn_pp = 0;           // 1: two-wave-group kernel for the 8-wave split-precision case (ovm_tune_set "attn_pp"); measured equal
                                     // to the lock-step kernel (6.36 vs 6.23 ms per ViT-L image, same box), so it stays an option
 void attn_set_pp(int v) { g_attn_pp = v; }
+// 1: the 4-wave x 64-query kernel (attn64.hip) for split precision. Built in round 3 to halve the LDS fragment traffic per MFMA; on
+// the chip it is SLOWER than 8 waves x 32 queries (339 vs 261 us per ViT-L launch at T = 4097, profiles/r03): with one wave per SIMD
+// nothing overlaps the softmax VALU work or the fragment latency. It stays selectable (bit-identical results) as the record of that
+// measurement; the 8-wave kernel remains the default.
+static int g_attn_q64 = 0;
+void attn_set_q64(int v) { g_attn_q64 = v; }
 static int g_attn_waves = 0;        // 0 = automatic (8 by default, 4 in co-run mode)
 void attn_set_waves(int v) { g_attn_waves = (v == 4 || v == 8) ? v : 0; }
 
@@ -724,6 +634,7 @@ int launch_attention(const AttnParams& p, int npass, hipStream_t s) {
   const int pad = g_attn_lds_pad;                  // experiment knob; the 3-slot rings (96 KB) already keep a workgroup alone on its CU
   if (npass == 3) {
     const int smem = OVM_ATTN_RD * 4 * 64 * 128 + pad;
+    if (nw == 8 && g_attn_q64 && !g_attn_pp) return launch_attention64(pm, tail_blocks, s);
     if (nw == 8 && g_attn_pp) {
       constexpr int smem_pp = 2 * 4 * 2 * 64 * 128;        // two 4-slot rings of hi + lo tiles = 128 KiB
       static bool setpp = false;

@@ -236,7 +236,7 @@ struct StageGeo { int h = 0, w = 0; WinMaps wm[2]; int* merge = nullptr; int h2 
 struct Plan {
   int H = 0, W = 0, T = 0;
   std::vector<int> ids, pids;
-  std::vector<void*> allocs;
+  std::vector<void*> allocs; size_t bytes = 0;      // device memory this plan holds (the plan cache's budget counts it)
   // text
   int* d_ids = nullptr; int* d_pids = nullptr; float* text_bias = nullptr; float* text_pos = nullptr;
   // swin
@@ -269,7 +269,7 @@ int pup(OvmGdino* g, Plan* pl, const std::vector<T>& v, T** out) {
   void* q = nullptr;
   size_t bytes = v.size() * sizeof(T); if (bytes == 0) bytes = 16;
   GCHECK(g, hipMalloc(&q, bytes));
-  pl->allocs.push_back(q);
+  pl->allocs.push_back(q); pl->bytes += bytes;
   if (!v.empty()) GCHECK(g, hipMemcpy(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   *out = (T*)q;
   return OVM_OK;
@@ -279,7 +279,7 @@ int pal(OvmGdino* g, Plan* pl, T** out, size_t count) {
   void* q = nullptr;
   size_t bytes = count * sizeof(T); if (bytes == 0) bytes = 16;
   GCHECK(g, hipMalloc(&q, bytes));
-  pl->allocs.push_back(q);
+  pl->allocs.push_back(q); pl->bytes += bytes;
   *out = (T*)q;
   return OVM_OK;
 }
@@ -1181,9 +1181,18 @@ int ovm_gdino_forward(OvmGdino* g, const OvmImage* image, const int32_t* token_i
     pl->arena_cap = dry.peak + 4096;
     void* q = nullptr;
     if (hipMalloc(&q, pl->arena_cap) != hipSuccess) { delete pl; g->err = "arena allocation failed"; return OVM_ERR_HIP; }
-    pl->allocs.push_back(q); pl->arena = (char*)q;
-    const int maxp = g->cfg.max_plans > 0 ? g->cfg.max_plans : 16;
-    while ((int)g->plans.size() >= maxp) { (void)hipDeviceSynchronize(); delete g->plans.back(); g->plans.pop_back(); }
+    pl->allocs.push_back(q); pl->arena = (char*)q; pl->bytes += pl->arena_cap;
+    // Least recently used plans go when the count or - what matters on a dataset with many aspect ratios - the bytes they hold
+    // together exceed the configured bounds (defaults: 128 plans, 32 GiB of the 288 GB).
+    const int maxp = g->cfg.max_plans > 0 ? g->cfg.max_plans : 128;
+    const size_t budget = (size_t)(g->cfg.plan_budget_mb > 0 ? g->cfg.plan_budget_mb : 32768) << 20;
+    size_t held = pl->bytes;
+    for (Plan* q2 : g->plans) held += q2->bytes;
+    while (!g->plans.empty() && ((int)g->plans.size() >= maxp || held > budget)) {
+      (void)hipDeviceSynchronize();
+      held -= g->plans.back()->bytes;
+      delete g->plans.back(); g->plans.pop_back();
+    }
   }
   g->plans.push_front(pl);
   g->last = pl;
@@ -1247,6 +1256,8 @@ int ovm_gdino_last_outputs(OvmGdino* g, const float** pred_logits, const float**
 int64_t ovm_gdino_debug_copy(OvmGdino* g, const char* name, void* dst, int64_t capacity_elems, ovm_stream_t stream) {
   if (!g || !g->last || !name) return OVM_ERR_INVALID;
   if (std::string(name) == "launches") return g->launches_last;
+  if (std::string(name) == "plans") return (int64_t)g->plans.size();                      // plan-cache occupancy (tests, bench)
+  if (std::string(name) == "plan_bytes") { int64_t b = 0; for (Plan* q : g->plans) b += (int64_t)q->bytes; return b; }
   auto it = g->last->taps.find(name);
   if (it == g->last->taps.end()) { g->err = std::string("unknown debug tensor ") + name; return OVM_ERR_INVALID; }
   if (it->second.second > capacity_elems) return OVM_ERR_CAPACITY;

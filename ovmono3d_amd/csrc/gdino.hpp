@@ -76,6 +76,7 @@ struct MsDeformParams {
   half_t* ohi; half_t* olo; int ldoh; // split fp16 (or null)
 };
 int launch_msdeform_fused(const MsDeformParams& p, hipStream_t s);
+void msdeform_set_vec(int v);
 
 // ---- small element-wise helpers of the decoder ---------------------------------------------------------------------------------
 // ref_out = sigmoid(delta + logit(clamp(ref, eps, 1 - eps)))  (iterative box refinement), [n][4]

@@ -459,6 +459,76 @@ __global__ __launch_bounds__(256) void msdeform_fused_kernel(const MsDeformParam
   }
 }
 
+// The common geometry (L * P = 16 samples per head, dh % 4 == 0): one thread per (query, head, FOUR channels). The softmax over the
+// 16 logits is evaluated once per thread into registers (the per-channel kernel above spends 48 expf per output element), the four
+// taps of a sample are float4 loads (8 lanes cover a head's 128-byte row), and every output element sees exactly the operations of
+// the per-channel kernel in the same order - the two kernels agree bit for bit.
+template <int LP>
+__global__ __launch_bounds__(256) void msdeform_fused4_kernel(const MsDeformParams p) {
+  const int dq = p.dh >> 2;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)p.Q * p.H * dq;
+  if (t >= total) return;
+  const int d = (int)(t % dq) * 4; long r = t / dq;
+  const int hh = (int)(r % p.H); const int q = (int)(r / p.H);
+  const float* offp = p.ow + (size_t)q * p.ldow + (size_t)hh * LP * 2;
+  const float* lgp = p.ow + (size_t)q * p.ldow + (size_t)p.H * LP * 2 + (size_t)hh * LP;
+  float lg[LP], off[2 * LP];
+#pragma unroll
+  for (int i = 0; i < LP; i += 4) *(f32x4*)(lg + i) = *(const f32x4*)(lgp + i);
+#pragma unroll
+  for (int i = 0; i < 2 * LP; i += 4) *(f32x4*)(off + i) = *(const f32x4*)(offp + i);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) mx = fmaxf(mx, lg[i]);
+  float den = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) { lg[i] = expf(lg[i] - mx); den += lg[i]; }
+  const float inv = 1.0f / den;
+  const float* rf = p.ref + (size_t)q * p.ldref;
+  const float r0 = rf[0], r1 = rf[1];
+  float mulx_b = 0.f, muly_b = 0.f;
+  if (p.mode != 0) { mulx_b = rf[2] * (0.5f / (float)p.P); muly_b = rf[3] * (0.5f / (float)p.P); }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int i = 0;
+  for (int l = 0; l < p.L; ++l) {
+    const int Hh = p.lh[l], Ww = p.lw[l];
+    const float* vb = p.value + (size_t)p.lstart[l] * p.ldv + (size_t)hh * p.dh + d;
+    float mulx, muly;
+    if (p.mode == 0) { mulx = 1.0f / (float)Ww; muly = 1.0f / (float)Hh; }
+    else { mulx = mulx_b; muly = muly_b; }
+    for (int pt = 0; pt < p.P; ++pt, ++i) {
+      const float lx = __fadd_rn(__fmul_rn(off[2 * i], mulx), r0);
+      const float ly = __fadd_rn(__fmul_rn(off[2 * i + 1], muly), r1);
+      const float gx = 2.f * lx - 1.f, gy = 2.f * ly - 1.f;
+      const float ix = ((gx + 1.f) * (float)Ww - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)Hh - 1.f) * 0.5f;
+      const float fx = floorf(ix), fy = floorf(iy);
+      const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+      const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (y0 >= 0 && y0 < Hh) {
+        if (x0 >= 0 && x0 < Ww) { const f32x4 a = *(const f32x4*)(vb + (size_t)(y0 * Ww + x0) * p.ldv); const float w_ = wy0 * wx0; v += w_ * a; }
+        if (x1 >= 0 && x1 < Ww) { const f32x4 a = *(const f32x4*)(vb + (size_t)(y0 * Ww + x1) * p.ldv); const float w_ = wy0 * wx1; v += w_ * a; }
+      }
+      if (y1 >= 0 && y1 < Hh) {
+        if (x0 >= 0 && x0 < Ww) { const f32x4 a = *(const f32x4*)(vb + (size_t)(y1 * Ww + x0) * p.ldv); const float w_ = wy1 * wx0; v += w_ * a; }
+        if (x1 >= 0 && x1 < Ww) { const f32x4 a = *(const f32x4*)(vb + (size_t)(y1 * Ww + x1) * p.ldv); const float w_ = wy1 * wx1; v += w_ * a; }
+      }
+      const float aw = lg[i] * inv;
+      acc += v * aw;
+    }
+  }
+  const int col = hh * p.dh + d;
+  if (p.out) *(f32x4*)(p.out + (size_t)q * p.ldo + col) = acc;
+  if (p.ohi) {
+    half4 h4, l4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { half_t h, lo; split_f16(acc[e], h, lo); h4[e] = h; l4[e] = lo; }
+    *(half4*)(p.ohi + (size_t)q * p.ldoh + col) = h4;
+    if (p.olo) *(half4*)(p.olo + (size_t)q * p.ldoh + col) = l4;
+  }
+}
+
 __global__ void box_refine_kernel(const float* __restrict__ delta, int ldd, const float* __restrict__ ref, float eps, float* __restrict__ out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * 4) return;
@@ -597,8 +667,17 @@ int launch_biattn(const BiAttnParams& p, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 
+static int g_msdeform_vec = 1;          // ovm_tune_set("msdeform_vec", 0): the one-thread-per-channel kernel
+void msdeform_set_vec(int v) { g_msdeform_vec = v; }
+
 int launch_msdeform_fused(const MsDeformParams& p, hipStream_t s) {
   if (p.L > 8 || p.Q <= 0) return p.Q <= 0 ? OVM_OK : OVM_ERR_CAPACITY;
+  const bool al16 = !(((uintptr_t)p.value | (uintptr_t)p.ow | (uintptr_t)p.out | (uintptr_t)p.ohi | (uintptr_t)p.olo) & 15);
+  if (g_msdeform_vec && p.L * p.P == 16 && p.dh % 4 == 0 && p.ldv % 4 == 0 && p.ldow % 4 == 0 && p.ldo % 4 == 0 && p.ldoh % 4 == 0 &&
+      (p.H * p.L * p.P * 2) % 4 == 0 && al16) {
+    hipLaunchKernelGGL(msdeform_fused4_kernel<16>, g1((long)p.Q * p.H * (p.dh / 4)), dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+  }
   hipLaunchKernelGGL(msdeform_fused_kernel, g1((long)p.Q * p.H * p.dh), dim3(256), 0, s, p);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }

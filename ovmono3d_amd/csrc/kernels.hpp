@@ -78,6 +78,9 @@ int launch_depth_resize(const float* Dp, int B, int Hd, int Wd, int G, float* ou
 int launch_resize_bilinear_f32(const float* src, int B, int Hd, int Wd, int Ho, int Wo, float* out, hipStream_t s);
 int launch_zero(void* p, size_t bytes, hipStream_t s);
 int launch_attention(const AttnParams& p, int npass, hipStream_t s);
+// attn64.hip: the 4-wave x 64-query form of the split-precision kernel (pm: Tq / main_blocks already set by launch_attention)
+int launch_attention64(const AttnParams& pm, int tail_blocks, hipStream_t s);
+void attn_set_q64(int v);
 void attn_set_tail_rows(int on);
 void attn_set_lds_pad(int v);
 void attn_set_waves(int v);

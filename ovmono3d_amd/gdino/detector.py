@@ -138,7 +138,8 @@ class NativeGroundingDino:
     cross-check of the engine; it is test infrastructure and not importable from the package.)"""
 
     def __init__(self, device: torch.device, state_dict: Dict[str, torch.Tensor], tokenizer, pixel_mean, pixel_std,
-                 cfg: GDinoConfig = GDinoConfig(), precision: int = 3, use_graphs: bool = True, max_plans: int = 16):
+                 cfg: GDinoConfig = GDinoConfig(), precision: int = 3, use_graphs: bool = True, max_plans: int = 0,
+                 plan_budget_mb: int = 0):
         if "model.text_projection.weight" not in state_dict:
             state_dict = convert_upstream_state_dict(state_dict)
         self.tok, self.mean, self.std = tokenizer, list(pixel_mean), list(pixel_std)
@@ -147,7 +148,7 @@ class NativeGroundingDino:
         from .engine import GdinoEngine
         # the reference hands GroundingDINO images[0][[2,1,0]]: the normalised, unpadded image with channels flipped (:146)
         self.engine = GdinoEngine(device, state_dict, cfg, pixel_mean=self.mean, pixel_std=self.std, flip_channels=True,
-                                  precision=precision, use_graphs=use_graphs, max_plans=max_plans)
+                                  precision=precision, use_graphs=use_graphs, max_plans=max_plans, plan_budget_mb=plan_budget_mb)
         self.dev = device
 
     def _tokens(self, caption: str):

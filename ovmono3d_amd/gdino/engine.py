@@ -19,7 +19,7 @@ from .config import GDinoConfig
 class GdinoEngine:
     def __init__(self, device: torch.device, state_dict: Dict[str, torch.Tensor], cfg: GDinoConfig = GDinoConfig(),
                  pixel_mean: Sequence[float] = (0.0, 0.0, 0.0), pixel_std: Sequence[float] = (1.0, 1.0, 1.0), flip_channels: bool = True,
-                 precision: int = 3, use_graphs: bool = True, max_plans: int = 16):
+                 precision: int = 3, use_graphs: bool = True, max_plans: int = 0, plan_budget_mb: int = 0):
         if device.type != "cuda":
             raise RuntimeError("the GroundingDINO engine runs on the HIP device only (no CPU fallback)")
         self.dev, self.cfg, self.L = device, cfg, _lib.load()
@@ -34,6 +34,7 @@ class GdinoEngine:
         for i in range(3):
             c.pixel_mean[i], c.pixel_std[i] = float(pixel_mean[i]), float(pixel_std[i])
         c.flip_channels, c.precision, c.use_graphs, c.max_plans = int(flip_channels), int(precision), int(use_graphs), int(max_plans)
+        c.plan_budget_mb = int(plan_budget_mb)          # 0 = library defaults: up to 128 plans within 32 GiB (LRU)
         # bool / integer buffers (relative_position_index ...) are not weights; tensors above 4-d do not occur
         host = {k: np.ascontiguousarray(v.detach().to(torch.float32).cpu().numpy()) for k, v in state_dict.items()
                 if torch.is_tensor(v) and v.dtype.is_floating_point and v.dim() <= 4}
@@ -103,3 +104,7 @@ class GdinoEngine:
 
     def launches(self) -> int:
         return int(self.L.ovm_gdino_debug_copy(self._h, b"launches", None, 0, self._stream()))
+
+    def debug_scalar(self, name: str) -> int:
+        """"plans": plans held by the cache; "plan_bytes": device memory they hold together; "launches": kernels of the last forward."""
+        return int(self.L.ovm_gdino_debug_copy(self._h, name.encode(), None, 0, self._stream()))

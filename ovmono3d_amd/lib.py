@@ -55,7 +55,7 @@ class OvmGdinoConfig(C.Structure):
         ("pe_temperature", C.c_float), ("eps", C.c_float), ("bert_heads", C.c_int32),
         ("swin_embed", C.c_int32), ("swin_depths", C.c_int32 * 4), ("swin_heads", C.c_int32 * 4), ("swin_window", C.c_int32),
         ("pixel_mean", C.c_float * 3), ("pixel_std", C.c_float * 3), ("flip_channels", C.c_int32), ("precision", C.c_int32),
-        ("use_graphs", C.c_int32), ("max_plans", C.c_int32),
+        ("use_graphs", C.c_int32), ("max_plans", C.c_int32), ("plan_budget_mb", C.c_int32),
     ]
 
 

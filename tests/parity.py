@@ -13,6 +13,8 @@ FIELDS = ("pred_boxes", "scores", "pred_bbox3D", "pred_center_cam", "pred_center
 
 # "1e-3 rel" element by element needs a floor under which "relative" has no meaning for an element of the field (a rotation entry
 # that is ~0, the x of an object on the optical axis): |a_i - b_i| / max(|b_i|, floor). Floors in the field's own unit.
+POSE_AMP_FLOOR = 10.0     # |p6| / min(|a1|, |a2 - (b1.a2) b1|) above which a detection's 6-D -> R map counts as near-degenerate
+
 ELEM_FLOOR = {"pred_boxes": 1.0,          # pixels (original resolution)
               "scores": 1e-2,
               "pred_bbox3D": 0.1,         # metres
@@ -102,9 +104,15 @@ def parity_report(inst, ref: Dict[str, torch.Tensor], box_tol: float = 2e-3) -> 
     if "_pose6d" in ref:
         n1, n2, amp = pose_conditioning(ref["_pose6d"][ok])
         pose["amplification_median"] = float(amp.median())
-        # the angle a 1e-3-relative perturbation of the raw 6-D vector may cause, per detection: 1e-3 x amplification
-        excess = ang / (1e-3 * amp)
-        pose["max_geodesic_over_1e-3xamp"] = float(excess.max())
+        # Near-degenerate Gram-Schmidt inputs (a2 almost parallel to a1, or a tiny a1): amplification above POSE_AMP_FLOOR. There
+        # "1e-3 on the matrix entries" is not a property of the arithmetic but of the input, so they are held to the ANGLE a
+        # 1e-3-relative perturbation of the raw 6-D vector causes at that conditioning (1e-3 x amplification rad); every other
+        # detection is held to 1e-3 on the entries like any float field.
+        ill = amp > POSE_AMP_FLOOR
+        pose["amplification_floor"] = POSE_AMP_FLOOR
+        pose["n_ill_conditioned"] = int(ill.sum())
+        pose["well_conditioned_max_entry_err"] = float(perr[~ill].max()) if bool((~ill).any()) else 0.0
+        pose["ill_conditioned_max_geodesic_over_1e-3xamp"] = float((ang[ill] / (1e-3 * amp[ill])).max()) if bool(ill.any()) else 0.0
         worst = torch.argsort(perr, descending=True)[:8].tolist()
         pose["worst"] = [{"oracle_idx": int(torch.nonzero(ok)[k]), "entry_err": float(perr[k]), "geodesic_rad": float(ang[k]),
                           "box_delta_px": float(box_px[k]), "n1": float(n1[k]), "n2": float(n2[k]), "amplification": float(amp[k])}
@@ -115,14 +123,17 @@ def parity_report(inst, ref: Dict[str, torch.Tensor], box_tol: float = 2e-3) -> 
 
 def parity_ok(rep: Dict, tol: float = 1e-3, pose_by_conditioning: bool = False) -> bool:
     """Every paired detection, every float field within `tol` (scale-relative, tests/common.py:rel_err), ids exact, nothing unpaired.
-    pose_by_conditioning (the end-to-end leg behind a 900-query detector only - the two routes hand the cube head 2D boxes that differ
-    in the last bits): pred_pose is held to `tol` as the ANGLE a tol-relative perturbation of the head's raw 6-D output may cause at
-    that detection's own conditioning (pose_conditioning), not to a blanket looser number."""
+    pose_by_conditioning (the end-to-end leg behind a proposal stage only - the two routes hand the cube head 2D boxes that differ in
+    the last bits): pred_pose is held to `tol` on the matrix entries for every detection whose 6-D -> R map is well conditioned
+    (amplification <= POSE_AMP_FLOOR) and, for the near-degenerate ones, to the ANGLE a tol-relative perturbation of the head's raw
+    6-D output causes at that detection's own conditioning - not to a blanket looser number. Measured on the headline configuration
+    (profiles/r03): 1 of 532 detections exceeds 1e-3 (1.3e-3); its a2 - (b1.a2) b1 has length 0.0030 against |a1| = 0.128
+    (amplification 49), its 2D boxes differ by 2.6e-4 px between the routes, its angle is 0.14 of the conditioned bound."""
     if rep["unmatched_oracle"] or rep["unmatched_hip"] or rep["class_id_mismatches"]:
         return False
     for k, v in rep["max_rel_err"].items():
-        if k == "pred_pose" and pose_by_conditioning and "max_geodesic_over_1e-3xamp" in rep.get("pose", {}):
-            if rep["pose"]["max_geodesic_over_1e-3xamp"] * 1e-3 > tol:
+        if k == "pred_pose" and pose_by_conditioning and "well_conditioned_max_entry_err" in rep.get("pose", {}):
+            if rep["pose"]["well_conditioned_max_entry_err"] > tol or rep["pose"]["ill_conditioned_max_geodesic_over_1e-3xamp"] * 1e-3 > tol:
                 return False
         elif v > tol:
             return False

@@ -417,7 +417,6 @@ def test_headline_config_on_coco_example_vs_hf_and_oracle(device):
     # threshold 0.001 act on scores that agree to ~1e-4: a proposal on the edge may flip), exact class ids and 1e-3 on every pair
     assert rep["unmatched_oracle"] <= max(2, rep["n_det_oracle"] // 100) and rep["unmatched_hip"] <= max(2, rep["n_det_oracle"] // 100), rep
     assert rep["class_id_mismatches"] == 0, rep
-    worst = {k: v for k, v in rep["max_rel_err"].items()}
     # (b) no near-ties: the HF route's boxes through the native cube branch on the native ViT-L features (identity pairing)
     from ovmono3d_amd.structures import Boxes, Instances
     images = model.preprocess_image([dict(inp, image=image.to(device))])
@@ -430,7 +429,8 @@ def test_headline_config_on_coco_example_vs_hf_and_oracle(device):
     print("same boxes through the native cube branch:", rep_b)
     assert rep_b["same_order"] and rep_b["matched"] == rep["n_det_oracle"], rep_b
     assert parity_ok(rep_b, 1e-3), rep_b
-    # (a) again, floats: the two GroundingDINO routes hand over boxes that differ by ~1e-6 relative (fp32 rounding; ~1e-3 px);
-    # the random-init pose head (6-D vectors of norm ~1e-2 through Gram-Schmidt) turns that into up to ~1e-3 on a few poses -
-    # conditioning of the synthetic checkpoint, as (b) shows (same boxes: 4e-4) - so pose gets 3e-3 here, everything else 1e-3
-    assert all(v <= (3e-3 if k == "pred_pose" else 1e-3) for k, v in worst.items()), rep
+    # (a) again, floats: every field within 1e-3; pred_pose within 1e-3 on every detection whose 6-D -> R map is well conditioned and,
+    # for near-degenerate Gram-Schmidt inputs (amplification > 10, tests/parity.py), within the angle a 1e-3-relative perturbation
+    # of the raw 6-D vector causes there. The detections beyond 1e-3, their 2D-box deltas and 6-D norms are printed (rep["pose"]).
+    print("pose, detection by detection:", rep["pose"])
+    assert parity_ok(dict(rep, unmatched_oracle=0, unmatched_hip=0), 1e-3, pose_by_conditioning=True), rep

@@ -255,3 +255,30 @@ def test_ovm_infer_error_after_fork_leaves_the_handle_usable(device):
         assert len(got) == len(want) >= 5
         for f in ("scores", "pred_bbox3D", "pred_pose"):
             assert torch.equal(got.get(f), want.get(f)), f
+
+
+def test_vectorised_deformable_sampling_is_bit_identical(device):
+    """msdeform_fused4_kernel (round 3: one thread per query x head x FOUR channels, the softmax over the 16 sample logits evaluated once
+    into registers, float4 taps) against the one-thread-per-channel kernel it replaces (ovm_tune_set msdeform_vec = 0): every output
+    element sees the same operations in the same order, so the whole forward - encoder memories, selected proposals, logits, boxes -
+    must agree bit for bit (encoder mode: reference points; decoder mode: reference boxes)."""
+    from ovmono3d_amd import lib
+    L = lib.load()
+    hf, _ = _small_hf_gdino()
+    g = torch.Generator().manual_seed(7)
+    img = torch.randint(0, 256, (3, 120, 168), dtype=torch.uint8, generator=g).to(device)
+    ids = [101, 500, 1012, 600, 601, 1012, 102]
+    outs = []
+    try:
+        for vec in (0, 1):
+            assert L.ovm_tune_set(b"msdeform_vec", vec) == 0
+            eng = _engine(device, hf.state_dict(), SMALL, use_graphs=False)
+            logits, boxes = eng.forward(img, ids)
+            S = sum((-(-120 // s)) * (-(-168 // s)) for s in (8, 16, 32, 64))
+            outs.append((logits.clone(), boxes.clone(), eng.debug("topk", (SMALL["num_queries"],), torch.int32).clone()))
+            del eng
+    finally:
+        L.ovm_tune_set(b"msdeform_vec", 1)
+    assert SMALL["n_levels"] * SMALL["n_points"] == 16, "the vectorised kernel covers L * P = 16 (else this test compares a kernel with itself)"
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
