@@ -497,7 +497,7 @@ def main():
                               "tests/parity.py:ELEM_FLOOR. Gate: class ids exact, every float field <= 1e-3 (max_rel_err)"
                               + ("; behind the proposal stage: same_boxes strict (identity pairing), end_to_end with <= 1 % of the detections "
                                  "flipped by discrete near-ties, pred_pose <= 1e-3 on every detection whose 6-D -> R map is well conditioned "
-                                 "(amplification <= 10) and, for near-degenerate Gram-Schmidt inputs, held to the angle a 1e-3-relative "
+                                 "(amplification <= 5) and, for near-degenerate Gram-Schmidt inputs, held to the angle a 1e-3-relative "
                                  "perturbation of the raw 6-D output causes at that conditioning (pose.* fields; tests/parity.py)" if proposal_stage else "")
                               + ("; batch_vs_batch1: every image of the batch equals its own batch-1 run within 1e-5 (pred_pose, which carries the 6-D head's conditioning, 1e-4), ids exact" if B > 1 else ""))
         parity["oracle"] = ("oracle/ restatement" + (" + Hugging Face GroundingDINO port" if use_gdino else "")

@@ -50,6 +50,10 @@ constexpr float kPShift = 14.0f;       // log2 of the scale the main kernel carr
 // overlap without relying on a partner wave. K tiles therefore run one tile ahead of V tiles (two
 // LDS rings with a phase offset). Scores are in log2 units (Q is pre-scaled by dh^-0.5 * log2 e), so the
 // probabilities are a bare v_exp_f32.
+#ifndef OVM_ATTN_ILV
+#define OVM_ATTN_ILV 0     // 1: consecutive MFMAs of a wave go to different accumulators instead of twelve in a row per accumulator - measured
+                           // equal (263 vs 261 us per ViT-L launch, profiles/r03: back-to-back accumulation is forwarded by the matrix pipe), +13 VGPRs
+#endif
 #ifndef OVM_ATTN_RD
 #define OVM_ATTN_RD 3      // 4 (three tiles in flight, 128 KB) measured no faster than 3
 #endif
@@ -118,6 +122,32 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
   };
   // S^T tile pair (64 keys x 32 queries) from a K slot
   auto qk = [&](const char* kb, f32x16* s) {
+#if OVM_ATTN_ILV
+    // consecutive MFMAs alternate between the two score tiles (per accumulator the order of the products is unchanged)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[i][e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      half8 kh[2], kl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = 32 * i + r;
+        const int off = row * 128 + swz128(row, 2 * st + h) * 16;
+        kh[i] = *(const half8*)(kb + off);
+        if (NPASS == 3) kl[i] = *(const half8*)(kb + PART + off);
+      }
+      if (NPASS == 3) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) s[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[i], qh[st], s[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) s[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[i], ql[st], s[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) s[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[i], qh[st], s[i], 0, 0, 0);
+    }
+#else
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -135,6 +165,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
         s[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[st], s[i], 0, 0, 0);
       }
     }
+#endif
   };
 
   f32x16 o0[2];
@@ -226,6 +257,29 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
       for (int e = 0; e < 16; ++e) o0[t][e] *= alpha;
     // ---- O^T += V^T P^T ----
     const char* vb = Vring + (it % RD) * SLOT;
+#if OVM_ATTN_ILV
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp) {
+        half8 vh[2], vl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int row = 32 * t + r;
+          const int off = row * 128 + swz128(row, 4 * i + 2 * sp + h) * 16;
+          vh[t] = *(const half8*)(vb + off);
+          if (NPASS == 3) vl[t] = *(const half8*)(vb + PART + off);
+        }
+        if (NPASS == 3) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[t], __builtin_bit_cast(half8, phu[i][sp]), o0[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[t], __builtin_bit_cast(half8, plu[i][sp]), o0[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[t], __builtin_bit_cast(half8, phu[i][sp]), o0[t], 0, 0, 0);
+      }
+#else
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int row = 32 * t + r;
@@ -243,6 +297,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const At
           o0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, __builtin_bit_cast(half8, phu[i][sp]), o0[t], 0, 0, 0);
         }
     }
+#endif
     if (!LAST) {
       if (RD >= 3) {
         // the next iteration needs K(it + 2) and V(it + 1), issued RD - 2 iterations ago; what was issued since may stay in flight

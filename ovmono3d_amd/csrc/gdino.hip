@@ -24,6 +24,7 @@
 #include "../../include/ovm3d.h"
 #include "det2d.hpp"
 #include "gdino.hpp"
+#include "dec_chain.hpp"
 #include "kernels.hpp"
 
 using namespace ovm;
@@ -56,8 +57,11 @@ struct Plan;
 namespace ovm {
 static int g_gdino_branches = 1;
 void set_gdino_branches(int v) { g_gdino_branches = v ? 1 : 0; }
+static int g_gdino_dec_chain = 1;      // decoder layers as row-chain kernels (dec_chain.hip); read at capture time, like the branches
+void set_gdino_dec_chain(int v) { g_gdino_dec_chain = v ? 1 : 0; }
 }  // namespace ovm
 using ovm::g_gdino_branches;
+using ovm::g_gdino_dec_chain;
 
 struct OvmGdino {
   OvmGdinoConfig cfg;
@@ -909,7 +913,36 @@ int forward_impl(Run& r) {
     float* b1 = r.f32((size_t)Q * D); float* b2 = r.f32((size_t)Q * D); float* delta = r.f32((size_t)Q * 4);
     float* refs[2] = {ref, r.f32((size_t)Q * 4)};
     int cur = 0;
-    for (int i = 0; i < NL; ++i) {
+    // Row-chain form of a layer (dec_chain.hip): everything but the query self-attention is local to a query row, so a workgroup
+    // walks 16 rows through the whole layer in LDS - 3 launches per layer instead of ~35 (ovm_tune_set "gdino_dec_chain" 0: the
+    // launch-per-op sequence below, kept as the cross-check).
+    const bool chain = g_gdino_dec_chain && dec_chain_supported(D, c.heads, c.ffn_dim, c.n_levels, c.n_points, T, g->npass);
+    auto cl = [](const Lin& w) { return ChainLin{w.hi, w.bias, w.N, w.K, w.Kpad}; };
+    auto cn = [](const Ln& w) { return ChainLn{w.g, w.b}; };
+    for (int i = 0; i < NL && chain; ++i) {
+      DecLayer& ly = g->dec[i];
+      float* rf = refs[cur];
+      DecChainParams dp; memset(&dp, 0, sizeof(dp));
+      dp.Q = Q; dp.D = D; dp.T = T; dp.heads = c.heads; dp.ffn = c.ffn_dim; dp.eps = eps;
+      dp.hs = hs; dp.ref = rf; dp.ref_next = (i + 1 < NL) ? refs[cur ^ 1] : nullptr;
+      dp.qpos = qpos; dp.qk = qk; dp.v = vq; dp.ctx = ctx;
+      dp.tk = tkv_all + (size_t)i * 2 * D; dp.tv = dp.tk + D; dp.ldt = NL * 2 * D;
+      dp.val = val_all + (size_t)i * D; dp.ldv = NL * D;
+      dp.L = c.n_levels; dp.P = c.n_points;
+      for (int l = 0; l < c.n_levels; ++l) { dp.lh[l] = pl->lh[l]; dp.lw[l] = pl->lw[l]; dp.lstart[l] = pl->lstart[l]; }
+      dp.ref0 = cl(g->ref_head[0]); dp.ref1 = cl(g->ref_head[1]); dp.sa_qk = cl(ly.sa.qk); dp.sa_v = cl(ly.sa.v); dp.sa_out = cl(ly.sa.out);
+      dp.ca_q = cl(ly.ca.q); dp.ca_out = cl(ly.ca.out); dp.offw = cl(ly.msda.offw); dp.msda_out = cl(ly.msda.out);
+      dp.fc1 = cl(ly.fc1); dp.fc2 = cl(ly.fc2);
+      if (i + 1 < NL) { dp.bb0 = cl(g->bbox[i][0]); dp.bb1 = cl(g->bbox[i][1]); dp.bb2 = cl(g->bbox[i][2]); }
+      dp.ln1 = cn(ly.ln1); dp.ln2 = cn(ly.ln2); dp.ln3 = cn(ly.ln3); dp.ln4 = cn(ly.ln4);
+      if (r.go()) r.chk(launch_dec_chain(dp, 0, s), "dec_chain_a");
+      mha_core(r, qk, 2 * D, qk + D, 2 * D, vq, D, Q, Q, ly.sa.heads, D, nullptr, 0, ctx, D);
+      if (r.go()) r.chk(launch_dec_chain(dp, 1, s), "dec_chain_b");
+      if (i == NL - 1) { if (r.go()) GCHECK(g, hipMemcpyAsync(last_ref, rf, sizeof(float) * (size_t)Q * 4, hipMemcpyDeviceToDevice, s)); }
+      r.tap(("dec_hs" + std::to_string(i)).c_str(), hs, (int64_t)Q * D);
+      if (i + 1 < NL) cur ^= 1;
+    }
+    for (int i = 0; i < NL && !chain; ++i) {
       DecLayer& ly = g->dec[i];
       float* rf = refs[cur];
       if (r.go()) r.chk(ovm_g_sine_embed(rf, Q, 4, D / 2, 10000.0f, sine, s), "sine_embed");

@@ -199,10 +199,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   if (EPI == EPI_QKV && ksplit == 1) vt_tile = (nb / (p.N / 3)) == 2;   // wave-uniform: head blocks are 64 wide
 #pragma unroll
   for (int ra = 0; ra < 2; ++ra) {
+    if (!vt_tile) {
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) *(f32x4*)(tile + (mi * 16 + fr) * TLD + ni * 16 + fq * 4) = acc[ra][mi][ni];
+        for (int ni = 0; ni < 4; ++ni) *(f32x4*)(tile + (mi * 16 + fr) * TLD + ni * 16 + fq * 4) = acc[ra][mi][ni];
+    } else {
+      // V^T tiles are staged TRANSPOSED ([d][token]): the store loop below reads a token per lane for one d at a time, which on the
+      // row-major image was 64 lanes at a stride of 68 floats = 8 lanes per bank (PMC r02: LDS conflict cycles 0.335 of the LDS
+      // instructions in the qkv GEMM against 0.13 in fc1, same main loop); transposed it is 64 consecutive floats.
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tile[(ni * 16 + fq * 4 + e) * TLD + mi * 16 + fr] = acc[ra][mi][ni][e];
+    }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int mrow0 = mb + ra * 64;
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         const int tp = (t & ~15) | (t & 3) | ((t & 4) << 1) | ((t & 8) >> 1);
         const size_t o0 = ((size_t)(b * p.heads + head) * 64) * p.Tpad + tp;
         for (int d = 0; d < 64; ++d) {
-          float x = tile[lane * TLD + d];
+          float x = tile[d * TLD + lane];
           if (p.bias) x += p.bias[nb + d];
           half_t hh, ll; split_f16(x, hh, ll);
           p.Vhi[o0 + (size_t)d * p.Tpad] = hh;

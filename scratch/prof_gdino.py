@@ -1,40 +1,36 @@
-import sys, os, time, torch
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-from ovmono3d_amd.gdino.detector import HashTokenizer
-from ovmono3d_amd.gdino.model import GDinoConfig, GroundingDinoNative
-from ovmono3d_amd.gdino.ops import Ops
-from ovmono3d_amd.util.synth_gdino import synth_gdino_model
-dev = torch.device("cuda:0")
-_, sd = synth_gdino_model(0)
-prec = int(os.environ.get("PREC", "3"))
-net = GroundingDinoNative(Ops(dev, prec), sd, GDinoConfig())
-H = W = 532
-x = torch.randn(H * W, 3, device=dev)
-ids = torch.tensor(HashTokenizer().encode("chair . dining table . sofa . potted plant . television . bookcase ."))
-for _ in range(3):
-    net.forward(x, H, W, ids)
-torch.cuda.synchronize()
-n = int(os.environ.get("N", "10"))
-t0 = time.time()
-for _ in range(n):
-    net.forward(x, H, W, ids)
-t1 = time.time()
-torch.cuda.synchronize()
-t2 = time.time()
-print(f"forward: host issue {(t1 - t0) / n * 1e3:.2f} ms, total {(t2 - t0) / n * 1e3:.2f} ms")
+"""Detector-only profile driver: the GroundingDINO engine (Swin-B / BERT-base / 900 queries, synthetic weights) on one 532 x 532 image,
+N forwards, for `rocprofv3 --kernel-trace --stats -- python3 scratch/prof_gdino.py` (graphs on by default: kernels inside a replayed
+graph are traced too)."""
+import os
+import sys
+import time
 
-from ovmono3d_amd.gdino.detector import NativeGroundingDino
-for use_graphs in (False, True):
-    det = NativeGroundingDino(dev, sd, HashTokenizer(), [103.53, 116.28, 123.675], [57.375, 57.12, 58.395], precision=prec, use_graphs=use_graphs)
-    im = torch.randint(0, 256, (3, H, W), dtype=torch.uint8, device=dev)
-    cap = "chair . dining table . sofa . potted plant . television . bookcase ."
-    for _ in range(4):
-        det(im, cap)
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for _ in range(n):
-        det(im, cap)
-    t1 = time.time()
-    torch.cuda.synchronize()
-    t2 = time.time()
-    print(f"detector graphs={use_graphs}: host issue {(t1 - t0) / n * 1e3:.2f} ms, total {(t2 - t0) / n * 1e3:.2f} ms")
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ovmono3d_amd import lib  # noqa: E402
+from ovmono3d_amd.gdino.engine import GdinoEngine  # noqa: E402
+from ovmono3d_amd.gdino.config import GDinoConfig  # noqa: E402
+from ovmono3d_amd.util.synth_gdino_weights import synth_gdino_state_dict  # noqa: E402
+
+dev = torch.device("cuda", 0)
+for kv in os.environ.get("OVM_TUNE", "").split(","):
+    if "=" in kv:
+        k, v = kv.split("=")
+        assert lib.load().ovm_tune_set(k.encode(), int(v)) == 0
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+hw = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (532, 532)
+eng = GdinoEngine(dev, synth_gdino_state_dict(0), GDinoConfig(), pixel_mean=[103.53, 116.28, 123.675], pixel_std=[57.375, 57.12, 58.395],
+                  use_graphs=os.environ.get("OVM_GRAPHS", "1") == "1")
+img = torch.randint(0, 256, (3,) + hw, dtype=torch.uint8, generator=torch.Generator().manual_seed(0)).to(dev)
+ids = [101] + [2000 + 7 * i for i in range(1, 7) for _ in (0, 1)][:9] + [102]
+ids = [101, 2023, 1012, 2024, 2025, 1012, 2026, 1012, 2027, 2028, 1012, 2029, 1012, 2030, 1012, 102]
+for _ in range(3):
+    eng.forward(img, ids)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n):
+    eng.forward(img, ids)
+torch.cuda.synchronize()
+print(f"detector alone: {(time.perf_counter() - t0) / n * 1e3:.3f} ms per forward, {eng.launches()} op launches")

@@ -274,11 +274,49 @@ def test_vectorised_deformable_sampling_is_bit_identical(device):
             assert L.ovm_tune_set(b"msdeform_vec", vec) == 0
             eng = _engine(device, hf.state_dict(), SMALL, use_graphs=False)
             logits, boxes = eng.forward(img, ids)
-            S = sum((-(-120 // s)) * (-(-168 // s)) for s in (8, 16, 32, 64))
             outs.append((logits.clone(), boxes.clone(), eng.debug("topk", (SMALL["num_queries"],), torch.int32).clone()))
             del eng
     finally:
         L.ovm_tune_set(b"msdeform_vec", 1)
-    assert SMALL["n_levels"] * SMALL["n_points"] == 16, "the vectorised kernel covers L * P = 16 (else this test compares a kernel with itself)"
+    from ovmono3d_amd.gdino.config import GDinoConfig
+    cfg = GDinoConfig(**SMALL)
+    assert cfg.n_levels * cfg.n_points == 16, "the vectorised kernel covers L * P = 16 (else this test compares a kernel with itself)"
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("size", ["small", "full"])
+def test_decoder_row_chain_matches_launch_per_op_decoder(device, size):
+    """dec_chain.hip (round 3): a decoder layer as two row-chain kernels around the query self-attention - 16 query rows per workgroup
+    resident in LDS through fourteen linears, four LayerNorms, the text cross-attention, the deformable sampling and the box update -
+    against the launch-per-op sequence it replaces (ovm_tune_set gdino_dec_chain = 0; itself checked against the HF port above).
+    Same operands, same three-pass products, fp32 everywhere else; what differs is summation order inside LayerNorm / softmax /
+    the FFN's chunked second layer: logits and boxes within 2e-5, the launch count drops by ~30 per layer."""
+    from ovmono3d_amd import lib
+    L = lib.load()
+    g = torch.Generator().manual_seed(11)
+    if size == "small":
+        hf, _ = _small_hf_gdino()
+        sd, cfgk, hw = hf.state_dict(), SMALL, (120, 168)
+        ids = [101, 500, 1012, 600, 601, 1012, 102]
+    else:
+        from ovmono3d_amd.util.synth_gdino_weights import synth_gdino_state_dict
+        sd, cfgk, hw = synth_gdino_state_dict(3), {}, (532, 709)
+        ids = [101, 2000 + 17, 1012, 2000 + 29, 2000 + 31, 1012, 2000 + 5, 1012, 102]
+    img = torch.randint(0, 256, (3,) + hw, dtype=torch.uint8, generator=g).to(device)
+    outs, launches = [], []
+    try:
+        for chain in (0, 1):
+            assert L.ovm_tune_set(b"gdino_dec_chain", chain) == 0
+            eng = _engine(device, sd, cfgk, use_graphs=False)
+            logits, boxes = eng.forward(img, ids)
+            outs.append((logits[:, :len(ids)].clone(), boxes.clone()))
+            launches.append(eng.launches())
+            del eng
+    finally:
+        L.ovm_tune_set(b"gdino_dec_chain", 1)
+    print(f"decoder row chain ({size}): {launches[0]} -> {launches[1]} kernel launches per forward")
+    assert launches[1] <= launches[0] - 15 * (2 if size == "small" else 6)          # (op wrappers counted, split-K reduce launches not included)
+    assert torch.isfinite(outs[1][0]).all() and torch.isfinite(outs[1][1]).all()
+    assert_close(outs[1][1], outs[0][1], 2e-5, "pred_boxes (row chain vs launch per op)")
+    assert_close(outs[1][0], outs[0][0], 2e-5, "pred_logits (row chain vs launch per op)")
