@@ -14,8 +14,10 @@
 //             512-wide chunks of the hidden layer (never materialised whole) + LN4;  box MLP (3 linears) + refine -> next ref
 //
 // Linear layers: v_mfma_f32_16x16x32_f16 with the WEIGHT rows on the MFMA's A side - read straight from global / L2 into registers
-// in the interleaved split image [n][k/32][hi 32 | lo 32] (every weight element is used once per workgroup, so LDS staging would
-// only add a hop) - and the 16 activation rows on the B side from a split-fp16 copy in LDS; three passes per product in the order of
+// (every weight element is used once per workgroup, so LDS staging would only add a hop) from a copy of the split image in
+// MFMA-FRAGMENT ORDER [tile of 16 rows][k-step][hi | lo][lane][8 halves]: one load instruction = 1 KiB contiguous (from the row-major
+// image a quarter-wave hits 16 different rows: 64 cache lines per instruction, 16 bytes used of each - measured 13 us per
+// 256 x 256 projection against 7 with this layout) - and the 16 activation rows on the B side from a split-fp16 copy in LDS; three passes per product in the order of
 // every other GEMM here (lo x hi, hi x lo, hi x hi; fp32 accumulate). 57 workgroups (900 / 16) x 8 waves; a layer is 3 launches.
 #include <hip/hip_runtime.h>
 #include "gemm.hpp"
@@ -36,10 +38,11 @@ struct Lds {
   half_t* xh; half_t* xl;                           // [R][XLD]
   float* u;                                         // union: FFN hidden chunk [R][KMAX + 4] | offsets+weights [R][NOW + 4] | sine [R][2D + 4] | scores
   int ldf;
+  int skip;                                         // -DOVM_DIAG builds: timing-ablation mask (DecChainParams::dbg_skip), else 0
 };
 
-__device__ __forceinline__ Lds carve(char* smem, int D) {
-  Lds l; l.ldf = D + 4;
+__device__ __forceinline__ Lds carve(char* smem, int D, int skip) {
+  Lds l; l.ldf = D + 4; l.skip = skip;
   float* f = (float*)smem;
   l.x0 = f; f += R * l.ldf; l.qp = f; f += R * l.ldf; l.t1 = f; f += R * l.ldf; l.t2 = f; f += R * l.ldf;
   l.xh = (half_t*)f; l.xl = l.xh + R * XLD;
@@ -50,10 +53,15 @@ __device__ __forceinline__ Lds carve(char* smem, int D) {
 // Y[R][ldy] (op)= act(X[R][K] (+ X2) . W[n_off .. n_off + N)[k_off .. k_off + K)^T + bias) (+ Res)        all activations in LDS, fp32
 //   accum: Y += (bias is then the caller's business: pass null); N a multiple of 16 (rows up to the weight's 128-row padding exist
 //   and are zero), Nvalid <= N columns are written. Ends WITHOUT a barrier: the caller synchronises before Y is read.
-__device__ __forceinline__ void chain_lin(const Lds l, const float* X, const float* X2, int ldx, int K, const ChainLin w, int k_off, int n_off, int N, int Nvalid,
-                          const float* bias, int act, const float* Res, int ldr, bool accum, float* Y, int ldy) {
+//   FULL: K is a multiple of 256 - every k-batch has its 8 steps, nothing is predicated around the burst loads.
+template <bool FULL>
+__device__ __forceinline__ void chain_lin_t(const Lds l, const float* X, const float* X2, int ldx, int K, const ChainLin w, int k_off, int n_off, int N,
+                                            int Nvalid, const float* bias, int act, const float* Res, int ldr, bool accum, float* Y, int ldy) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __syncthreads();                                        // X complete; previous readers of the split copy done
+#ifdef OVM_DIAG
+  if (!(l.skip & 16))
+#endif
   for (int i = tid; i < R * (K >> 2); i += NT) {          // fp32 -> split fp16, four at a time
     const int row = i / (K >> 2), c = (i - row * (K >> 2)) << 2;
     f32x4 v = *(const f32x4*)(X + row * ldx + c);
@@ -67,36 +75,37 @@ __device__ __forceinline__ void chain_lin(const Lds l, const float* X, const flo
   __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
   const int ks_n = K >> 5;
-  const size_t wld = (size_t)2 * w.Kpad;
-  // Work unit = (16-column tile, batch of up to 8 k-steps). A unit's 16 weight fragments (hi + lo, 16 B per lane each) are loaded in
-  // one burst, and the burst of unit u + 1 is issued BEFORE the MFMAs of unit u: with 57 workgroups on the chip nothing but the
-  // loads in flight hides the ~1 us L2 latency (a first version that waited per four k-steps ran the whole decoder slower than the
-  // launch-per-op sequence it replaces). The compiler's wait-count pass turns the program order into vmcnt(16) in front of unit u.
+  // Work unit = (16-column tile, batch of up to 8 k-steps). A unit's 16 weight fragments (hi + lo, 16 B per lane each; 1 KiB
+  // contiguous per load instruction in the fragment-ordered image) are loaded in one burst, and the burst of unit u + 1 is issued
+  // BEFORE the MFMAs of unit u: with 57 workgroups on the chip only the loads in flight hide the memory latency. The bursts are
+  // UNCONDITIONAL (past the end they re-load the last unit): a burst inside an `if` makes the compiler wait for the older buffer
+  // with a count that also drains the new burst (one static vmcnt must hold on both paths) - no overlap at all.
   const int nb = (ks_n + 7) >> 3;                              // k-batches per tile
   const int units = ((N >> 4) - wave + NWV - 1) / NWV * nb;    // this wave's tiles x batches (tiles wave, wave + NWV, ...)
+  const int KS = w.Kpad >> 5;                                  // k-steps of the whole matrix (stride between tiles of the image)
   half8 wb[2][16];
-  auto wptr = [&](int u) {
-    const int tile = wave + (u / nb) * NWV, kb = u - (u / nb) * nb;
-    return w.w + (size_t)(n_off + tile * 16 + fr) * wld + (size_t)((k_off >> 5) + kb * 8) * 64 + fq * 8;
-  };
   auto wload = [&](int u, half8* dst) {
-    const half_t* wp = wptr(u);
-    const int kb = u % nb, nks = (ks_n - kb * 8) < 8 ? (ks_n - kb * 8) : 8;
+    const int tile = wave + (u / nb) * NWV, kb = u - (u / nb) * nb;
+    const half_t* wp = w.w + ((size_t)((n_off >> 4) + tile) * KS + (size_t)((k_off >> 5) + kb * 8)) * 1024 + lane * 8;
+    const int nks = FULL ? 8 : ((ks_n - kb * 8) < 8 ? (ks_n - kb * 8) : 8);
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      if (j < nks) { dst[2 * j] = *(const half8*)(wp + j * 64); dst[2 * j + 1] = *(const half8*)(wp + j * 64 + 32); }
+      if (FULL || j < nks) { dst[2 * j] = *(const half8*)(wp + j * 1024); dst[2 * j + 1] = *(const half8*)(wp + j * 1024 + 512); }
   };
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   auto compute = [&](int u, const half8* wbuf) {
     const int tile = wave + (u / nb) * NWV, kb = u - (u / nb) * nb;
-    const int nks = (ks_n - kb * 8) < 8 ? (ks_n - kb * 8) : 8;
+    const int nks = FULL ? 8 : ((ks_n - kb * 8) < 8 ? (ks_n - kb * 8) : 8);
     const half_t* xhp = l.xh + fr * XLD + fq * 8 + kb * 256;
     const half_t* xlp = l.xl + fr * XLD + fq * 8 + kb * 256;
     if (kb == 0) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      if (j < nks) {
+      if (FULL || j < nks) {
         const half8 wh = wbuf[2 * j], wl = wbuf[2 * j + 1];
+#ifdef OVM_DIAG
+        if (l.skip & 32) { asm volatile("" ::"v"(wh), "v"(wl)); continue; }
+#endif
         const half8 xh = *(const half8*)(xhp + j * 32);
         const half8 xl = *(const half8*)(xlp + j * 32);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc, 0, 0, 0);
@@ -120,15 +129,30 @@ __device__ __forceinline__ void chain_lin(const Lds l, const float* X, const flo
       }
     }
   };
-  if (units > 0) wload(0, wb[0]);
-  for (int u = 0; u < units; u += 2) {                         // unrolled by two: the buffer a unit reads is fixed at compile time
-    if (u + 1 < units) wload(u + 1, wb[1]);
-    compute(u, wb[0]);
-    if (u + 1 < units) {
-      if (u + 2 < units) wload(u + 2, wb[0]);
-      compute(u + 1, wb[1]);
+  if (units > 0) {
+#ifdef OVM_DIAG
+    if (l.skip & 64) {                                         // no weight loads at all (garbage operands): what the MFMA / LDS side costs alone
+      for (int u = 0; u < units; ++u) compute(u, wb[0]);
+      return;
+    }
+#endif
+    wload(0, wb[0]);
+    for (int u = 0; u < units; u += 2) {                       // unrolled by two: the buffer a unit reads is fixed at compile time
+      wload(u + 1 < units ? u + 1 : units - 1, wb[1]);
+      compute(u, wb[0]);
+      wload(u + 2 < units ? u + 2 : units - 1, wb[0]);
+      if (u + 1 < units) compute(u + 1, wb[1]);
     }
   }
+}
+
+__device__ __forceinline__ void chain_lin(const Lds l, const float* X, const float* X2, int ldx, int K, const ChainLin w, int k_off, int n_off, int N,
+                                          int Nvalid, const float* bias, int act, const float* Res, int ldr, bool accum, float* Y, int ldy) {
+#ifdef OVM_DIAG
+  if (l.skip & 2) { __syncthreads(); return; }
+#endif
+  if ((K & 255) == 0) chain_lin_t<true>(l, X, X2, ldx, K, w, k_off, n_off, N, Nvalid, bias, act, Res, ldr, accum, Y, ldy);
+  else chain_lin_t<false>(l, X, X2, ldx, K, w, k_off, n_off, N, Nvalid, bias, act, Res, ldr, accum, Y, ldy);
 }
 
 // LayerNorm of the R rows of X (LDS) -> Y (LDS, may alias X): 32 lanes per row
@@ -167,16 +191,19 @@ __device__ __forceinline__ void store_rows(const float* src, int lds_, int row0,
 // ------------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void dec_chain_a_kernel(const DecChainParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const Lds l = carve(smem, p.D);
+  const Lds l = carve(smem, p.D, p.dbg_skip);
   const int D = p.D, row0 = blockIdx.x * R, tid = threadIdx.x;
   load_rows(p.hs, D, row0, p.Q, D, l.x0, l.ldf);
   // sine embedding of the reference boxes (DETR convention: slots [y, x, w, h], temperature 10000): u[row][slot * F + f]
   const int F = D >> 1, lds_s = 2 * D + 4;
+#ifdef OVM_DIAG
+  if (!(p.dbg_skip & 1))
+#endif
   for (int i = tid; i < R * 4 * F; i += NT) {
     const int row = i / (4 * F), rem = i - row * 4 * F, slot = rem / F, f = rem - slot * F;
     int gr = row0 + row; if (gr > p.Q - 1) gr = p.Q - 1;
     const int c = slot == 0 ? 1 : (slot == 1 ? 0 : slot);
-    const float dim_t = powf(10000.0f, 2.f * (float)(f / 2) / (float)F);
+    const float dim_t = p.sine_dim_t[f >> 1];                 // 10000^(2 (f / 2) / F), tabulated at create (powf per element: 13 us per layer)
     const float e = p.ref[(size_t)gr * 4 + c] * 6.283185307179586f / dim_t;
     l.u[row * lds_s + rem] = (f & 1) ? cosf(e) : sinf(e);
   }
@@ -198,7 +225,7 @@ __global__ __launch_bounds__(NT) void dec_chain_a_kernel(const DecChainParams p)
 // ------------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void dec_chain_b_kernel(const DecChainParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const Lds l = carve(smem, p.D);
+  const Lds l = carve(smem, p.D, p.dbg_skip);
   const int D = p.D, row0 = blockIdx.x * R, tid = threadIdx.x;
   const int H = p.heads, dh = D / H;
   load_rows(p.hs, D, row0, p.Q, D, l.x0, l.ldf);
@@ -210,6 +237,9 @@ __global__ __launch_bounds__(NT) void dec_chain_b_kernel(const DecChainParams p)
   // ---- text cross-attention: q = (hs + qpos) W_q; scores over the T text tokens per (row, head); softmax; values
   chain_lin(l, l.x0, l.qp, l.ldf, D, p.ca_q, 0, 0, D, D, p.ca_q.bias, 0, nullptr, 0, false, l.t1, l.ldf);
   __syncthreads();
+#ifdef OVM_DIAG
+  if (!(p.dbg_skip & 4))
+#endif
   {
     const int T = p.T, npair = R * H;
     const float scale = 1.0f / sqrtf((float)dh);
@@ -250,6 +280,9 @@ __global__ __launch_bounds__(NT) void dec_chain_b_kernel(const DecChainParams p)
   const int LP = p.L * p.P, NOW = H * LP * 3, ldo = NOW + 4;
   chain_lin(l, l.x0, l.qp, l.ldf, D, p.offw, 0, 0, (NOW + 15) & ~15, NOW, p.offw.bias, 0, nullptr, 0, false, l.u, ldo);
   __syncthreads();
+#ifdef OVM_DIAG
+  if (!(p.dbg_skip & 8))
+#endif
   {
     const int dq = dh >> 2;
     for (int i = tid; i < R * H * dq; i += NT) {

@@ -5,7 +5,8 @@
 
 namespace ovm {
 
-struct ChainLin { const half_t* w; const float* bias; int N, K, Kpad; };   // interleaved split image [Npad][Kpad/32][hi 32 | lo 32]
+// w: the split weight image in MFMA-fragment order [Npad/16][Kpad/32][hi | lo][lane 0..63][8 halves] (gdino.hip: make_frag)
+struct ChainLin { const half_t* w; const float* bias; int N, K, Kpad; };
 struct ChainLn { const float* g; const float* b; };
 
 struct DecChainParams {
@@ -13,6 +14,7 @@ struct DecChainParams {
   float eps;
   float* hs;                        // [Q][D] decoder state: chain B updates it in place
   const float* ref;                 // [Q][4] this layer's reference boxes (cx, cy, w, h)
+  const float* sine_dim_t;          // [D / 4]: 10000^(2 i / (D / 2)) for i = 0 .. D / 4 - 1 (sine embedding's frequency table)
   float* ref_next;                  // [Q][4] refined boxes for the next layer, or null (last layer)
   float* qpos;                      // [Q][D]  query position embedding (chain A writes, chain B reads)
   float* qk; float* v;              // [Q][2D] = [q | k], [Q][D]: operands of the self-attention (chain A writes)
@@ -22,6 +24,8 @@ struct DecChainParams {
   int L, P; int lh[8], lw[8], lstart[8];
   ChainLin ref0, ref1, sa_qk, sa_v, sa_out, ca_q, ca_out, offw, msda_out, fc1, fc2, bb0, bb1, bb2;
   ChainLn ln1, ln2, ln3, ln4;
+  unsigned long long* dbg_stamps;   // -DOVM_DIAG: s_memtime stamps of workgroup 0 (chain A: [0..31], chain B: [32..95])
+  int dbg_skip;                     // -DOVM_DIAG builds only (env OVM_DEC_CHAIN_SKIP): timing ablations, results are wrong when non-zero
 };
 
 bool dec_chain_supported(int D, int heads, int ffn, int L, int P, int T, int npass);

@@ -33,6 +33,7 @@ namespace {
 
 struct Lin {                       // packed nn.Linear: split-fp16 weight image (gemm.hpp layout) + fp32 bias
   half_t* hi = nullptr; half_t* lo = nullptr; float* bias = nullptr;
+  half_t* frag = nullptr;          // decoder weights only: the same image in MFMA-fragment order (make_frag), for the row-chain kernels
   int N = 0, K = 0, Kpad = 0;
 };
 struct Ln { float* g = nullptr; float* b = nullptr; };
@@ -63,11 +64,15 @@ void set_gdino_dec_chain(int v) { g_gdino_dec_chain = v ? 1 : 0; }
 using ovm::g_gdino_branches;
 using ovm::g_gdino_dec_chain;
 
+constexpr size_t kSlabBytes = (size_t)256 << 20;
+
 struct OvmGdino {
   OvmGdinoConfig cfg;
   int device = 0, npass = 3;
   std::string err;
   std::vector<void*> allocs;
+  char* slab = nullptr; size_t slab_off = 0, slab_cap = 0;      // current slab of dmal()
+  float* sine_dim_t = nullptr;                                 // [d_model / 4] frequency table of the decoder's sine embedding (dec_chain.hip)
   // ---- weights
   float *word = nullptr, *posemb = nullptr, *typemb = nullptr; Ln emb_ln; int bertD = 0, n_pos = 0, vocab = 0;
   std::vector<BertLayer> bert;
@@ -119,13 +124,22 @@ int get(OvmGdino* g, const WMap& wm, const std::string& name, const OvmTensor** 
   return OVM_OK;
 }
 
+// Weights and tables live in a few large slabs, not in one hipMalloc each: ~700 separate allocations scatter the checkpoint over as
+// many small VM mappings, and the latency-bound kernels of this branch (every workgroup touches every page of a weight matrix once)
+// then pay an address-translation miss per 4-KiB page; a slab is mapped with large fragments.
 template <typename T>
 int dmal(OvmGdino* g, T** p, size_t count) {
-  void* q = nullptr;
   size_t bytes = count * sizeof(T); if (bytes == 0) bytes = 16;
-  GCHECK(g, hipMalloc(&q, bytes));
-  g->allocs.push_back(q);
-  *p = (T*)q;
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (g->slab_off + bytes > g->slab_cap) {
+    const size_t cap = bytes > kSlabBytes ? bytes : kSlabBytes;
+    void* q = nullptr;
+    GCHECK(g, hipMalloc(&q, cap));
+    g->allocs.push_back(q);
+    g->slab = (char*)q; g->slab_cap = cap; g->slab_off = 0;
+  }
+  *p = (T*)(g->slab + g->slab_off);
+  g->slab_off += bytes;
   return OVM_OK;
 }
 
@@ -169,6 +183,30 @@ int pack_host(OvmGdino* g, const std::vector<float>& w, const std::vector<float>
   out->N = N; out->K = K; out->Kpad = Kpad;
   out->bias = nullptr;
   if (!bias.empty()) RCHECK(g, up_vec(g, bias, &out->bias));
+  return OVM_OK;
+}
+
+// The row-chain kernels (dec_chain.hip) feed weight fragments from global memory straight into v_mfma_f32_16x16x32_f16: lane l wants
+// row l % 16, k-chunk l / 16 of a 16-row tile - read from the row-major image that is 16 different rows per quarter-wave, 64 cache
+// lines per load instruction with 16 bytes used of each (measured: ~13 us per 256 x 256 projection, 20 GB/s per CU). This copy holds
+// the image in the order the lanes consume it: [tile of 16 rows][k-step of 32][hi | lo][lane 0..63][8 halves] - one load
+// instruction = 1 KiB contiguous.
+int make_frag(OvmGdino* g, Lin* w) {
+  if (g->npass != 3 || !w->hi) return OVM_OK;
+  const int Npad = (w->N + 127) / 128 * 128, KS = w->Kpad / 32;
+  const size_t n = (size_t)Npad * 2 * w->Kpad;
+  std::vector<half_t> src(n), dst(n);
+  GCHECK(g, hipMemcpy(src.data(), w->hi, n * sizeof(half_t), hipMemcpyDeviceToHost));
+  for (int tile = 0; tile < Npad / 16; ++tile)
+    for (int ks = 0; ks < KS; ++ks)
+      for (int part = 0; part < 2; ++part)
+        for (int lane = 0; lane < 64; ++lane) {
+          const size_t so = (size_t)(tile * 16 + (lane & 15)) * 2 * w->Kpad + (size_t)ks * 64 + part * 32 + (lane >> 4) * 8;
+          const size_t dof = ((((size_t)tile * KS + ks) * 2 + part) * 64 + lane) * 8;
+          for (int e = 0; e < 8; ++e) dst[dof + e] = src[so + e];
+        }
+  RCHECK(g, dmal(g, &w->frag, n));
+  GCHECK(g, hipMemcpy(w->frag, dst.data(), n * sizeof(half_t), hipMemcpyHostToDevice));
   return OVM_OK;
 }
 
@@ -917,13 +955,14 @@ int forward_impl(Run& r) {
     // walks 16 rows through the whole layer in LDS - 3 launches per layer instead of ~35 (ovm_tune_set "gdino_dec_chain" 0: the
     // launch-per-op sequence below, kept as the cross-check).
     const bool chain = g_gdino_dec_chain && dec_chain_supported(D, c.heads, c.ffn_dim, c.n_levels, c.n_points, T, g->npass);
-    auto cl = [](const Lin& w) { return ChainLin{w.hi, w.bias, w.N, w.K, w.Kpad}; };
+    auto cl = [](const Lin& w) { return ChainLin{w.frag, w.bias, w.N, w.K, w.Kpad}; };
     auto cn = [](const Ln& w) { return ChainLn{w.g, w.b}; };
     for (int i = 0; i < NL && chain; ++i) {
       DecLayer& ly = g->dec[i];
       float* rf = refs[cur];
       DecChainParams dp; memset(&dp, 0, sizeof(dp));
       dp.Q = Q; dp.D = D; dp.T = T; dp.heads = c.heads; dp.ffn = c.ffn_dim; dp.eps = eps;
+      dp.sine_dim_t = g->sine_dim_t;
       dp.hs = hs; dp.ref = rf; dp.ref_next = (i + 1 < NL) ? refs[cur ^ 1] : nullptr;
       dp.qpos = qpos; dp.qk = qk; dp.v = vq; dp.ctx = ctx;
       dp.tk = tkv_all + (size_t)i * 2 * D; dp.tv = dp.tk + D; dp.ldt = NL * 2 * D;
@@ -935,7 +974,26 @@ int forward_impl(Run& r) {
       dp.fc1 = cl(ly.fc1); dp.fc2 = cl(ly.fc2);
       if (i + 1 < NL) { dp.bb0 = cl(g->bbox[i][0]); dp.bb1 = cl(g->bbox[i][1]); dp.bb2 = cl(g->bbox[i][2]); }
       dp.ln1 = cn(ly.ln1); dp.ln2 = cn(ly.ln2); dp.ln3 = cn(ly.ln3); dp.ln4 = cn(ly.ln4);
+#ifdef OVM_DIAG
+      if (const char* e = getenv("OVM_DEC_CHAIN_SKIP")) dp.dbg_skip = atoi(e);
+      static unsigned long long* d_st = nullptr;
+      if (getenv("OVM_DEC_CHAIN_STAMPS") && i == 0 && !dry) {
+        if (!d_st) { (void)hipMalloc((void**)&d_st, 96 * 8); }
+        (void)hipMemsetAsync(d_st, 0, 96 * 8, s);
+        dp.dbg_stamps = d_st;
+      }
+#endif
       if (r.go()) r.chk(launch_dec_chain(dp, 0, s), "dec_chain_a");
+#ifdef OVM_DIAG
+      if (dp.dbg_stamps && r.go()) {
+        unsigned long long hst[96];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(hst, dp.dbg_stamps, sizeof(hst), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[dec_chain_a stamps, cycles since entry]");
+        for (int k = 1; k < 32 && hst[k]; ++k) fprintf(stderr, " %llu", hst[k] - hst[0]);
+        fprintf(stderr, "\n");
+      }
+#endif
       mha_core(r, qk, 2 * D, qk + D, 2 * D, vq, D, Q, Q, ly.sa.heads, D, nullptr, 0, ctx, D);
       if (r.go()) r.chk(launch_dec_chain(dp, 1, s), "dec_chain_b");
       if (i == NL - 1) { if (r.go()) GCHECK(g, hipMemcpyAsync(last_ref, rf, sizeof(float) * (size_t)Q * 4, hipMemcpyDeviceToDevice, s)); }
@@ -1162,6 +1220,19 @@ int ovm_gdino_create(const OvmGdinoConfig* cfg, const OvmTensor* weights, int32_
   g->bbox.resize(c.dec_layers);
   for (int i = 0; i < c.dec_layers; ++i)
     for (int k = 0; k < 3; ++k) RCHECK(g, pack_lin(g, wm, "bbox_embed." + std::to_string(i) + ".layers." + std::to_string(k), &g->bbox[i][k]));
+  {
+    const int F = D / 2;
+    std::vector<float> dt((size_t)F / 2);
+    for (int i = 0; i < F / 2; ++i) dt[i] = powf(10000.0f, 2.f * (float)i / (float)F);       // sine_embed_kernel's dim_t for f / 2 = i
+    RCHECK(g, up_vec(g, dt, &g->sine_dim_t));
+  }
+  // fragment-ordered copies of everything the decoder's row-chain kernels multiply by
+  for (int k = 0; k < 2; ++k) RCHECK(g, make_frag(g, &g->ref_head[k]));
+  for (int i = 0; i < c.dec_layers; ++i) {
+    DecLayer& ly = g->dec[i];
+    for (Lin* w : {&ly.sa.qk, &ly.sa.v, &ly.sa.out, &ly.ca.q, &ly.ca.out, &ly.msda.offw, &ly.msda.out, &ly.fc1, &ly.fc2}) RCHECK(g, make_frag(g, w));
+    if (i + 1 < c.dec_layers) for (int k = 0; k < 3; ++k) RCHECK(g, make_frag(g, &g->bbox[i][k]));
+  }
   GCHECK(g, hipDeviceSynchronize());
   return OVM_OK;
 }

@@ -14,6 +14,8 @@ from ovmono3d_amd.gdino.engine import GdinoEngine  # noqa: E402
 from ovmono3d_amd.gdino.config import GDinoConfig  # noqa: E402
 from ovmono3d_amd.util.synth_gdino_weights import synth_gdino_state_dict  # noqa: E402
 
+if os.environ.get("OVM_LIB"):                     # scratch only: a diagnostic build of the library (-DOVM_DIAG)
+    lib.LIB_PATH = os.environ["OVM_LIB"]
 dev = torch.device("cuda", 0)
 for kv in os.environ.get("OVM_TUNE", "").split(","):
     if "=" in kv:
