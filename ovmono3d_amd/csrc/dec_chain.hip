@@ -310,15 +310,16 @@ __global__ __launch_bounds__(NT) void dec_chain_b_kernel(const DecChainParams p)
           const float fx = floorf(ix), fy = floorf(iy);
           const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
           const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+          // branch-free taps (see msdeform_fused4_kernel): clamped address, weight 0 outside the level
+          const bool vx0 = x0 >= 0 && x0 < Ww, vx1 = x1 >= 0 && x1 < Ww, vy0 = y0 >= 0 && y0 < Hh, vy1 = y1 >= 0 && y1 < Hh;
+          const int cx0 = min(max(x0, 0), Ww - 1), cx1 = min(max(x1, 0), Ww - 1), cy0 = min(max(y0, 0), Hh - 1), cy1 = min(max(y1, 0), Hh - 1);
+          const f32x4 a00 = *(const f32x4*)(vb + (size_t)(cy0 * Ww + cx0) * p.ldv), a01 = *(const f32x4*)(vb + (size_t)(cy0 * Ww + cx1) * p.ldv);
+          const f32x4 a10 = *(const f32x4*)(vb + (size_t)(cy1 * Ww + cx0) * p.ldv), a11 = *(const f32x4*)(vb + (size_t)(cy1 * Ww + cx1) * p.ldv);
           f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (y0 >= 0 && y0 < Hh) {
-            if (x0 >= 0 && x0 < Ww) { const f32x4 a = *(const f32x4*)(vb + (size_t)(y0 * Ww + x0) * p.ldv); const float w_ = wy0 * wx0; v += w_ * a; }
-            if (x1 >= 0 && x1 < Ww) { const f32x4 a = *(const f32x4*)(vb + (size_t)(y0 * Ww + x1) * p.ldv); const float w_ = wy0 * wx1; v += w_ * a; }
-          }
-          if (y1 >= 0 && y1 < Hh) {
-            if (x0 >= 0 && x0 < Ww) { const f32x4 a = *(const f32x4*)(vb + (size_t)(y1 * Ww + x0) * p.ldv); const float w_ = wy1 * wx0; v += w_ * a; }
-            if (x1 >= 0 && x1 < Ww) { const f32x4 a = *(const f32x4*)(vb + (size_t)(y1 * Ww + x1) * p.ldv); const float w_ = wy1 * wx1; v += w_ * a; }
-          }
+          { const float w_ = (vy0 && vx0) ? wy0 * wx0 : 0.f; v += w_ * a00; }
+          { const float w_ = (vy0 && vx1) ? wy0 * wx1 : 0.f; v += w_ * a01; }
+          { const float w_ = (vy1 && vx0) ? wy1 * wx0 : 0.f; v += w_ * a10; }
+          { const float w_ = (vy1 && vx1) ? wy1 * wx1 : 0.f; v += w_ * a11; }
           const float aw = expf(lgp[s] - mx) * inv;
           acc += v * aw;
         }
