@@ -34,8 +34,13 @@ __device__ __forceinline__ int frag_off(int row, int chunk) { return row * 128 +
 // STAMP = 1 is a diagnostic build (never used by the engine): every wave of workgroup 0 records s_memtime after each barrier of
 // the first k-groups into the unused top 32 KiB of the LDS and dumps them to p.stamps at the end (cdna_hip_programming.md 7,
 // "In-kernel stamps": read the SHARES of the segments, not the run time of this build).
-template <int EPI, int STAMP = 0>
+// NTW = 16-column MFMA tiles per wave along N: 4 -> the 256 x 256 tile; 3 -> a 256 x 192 tile (W1 holds 64 rows). The qkv contraction
+// of a ViT-L image (M = 4097, N = 3072) is 16 x 12 = 192 tiles of 256 x 256 - a quarter of the CUs idle for the whole launch - but
+// 16 x 16 = 256 tiles of 256 x 192: one full round at 3/4 of the per-tile work.
+template <int EPI, int STAMP = 0, int NTW = 4>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
+  constexpr int BN = 64 * NTW;
+  constexpr int WP = (NTW == 4) ? 4 : 3;      // LDS-DMA pieces a wave issues per k-group for the two W half-tiles
   if ((int)blockIdx.x >= p.main_tiles) { gemm_tail_body<3, EPI, A_ROWMAJOR, true>(p, (int)blockIdx.x - p.main_tiles); return; }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned long long t_entry = STAMP ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
   const int tm = first_m + (pid % in_group) % gsz;
   const int tn = (pid % in_group) / gsz;
-  const int m0 = tm * 256, n0 = tn * 256;
+  const int m0 = tm * 256, n0 = tn * BN;
   const int nk_all = p.K / 32;
   const int kt0 = (ksplit > 1) ? ks * p.kchunk : 0;
   const int nk = (ksplit > 1) ? ((nk_all - kt0 < p.kchunk) ? nk_all - kt0 : p.kchunk) : nk_all;
@@ -83,12 +88,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     char* base = smem + (2 + hf) * kRegion + (t & 1) * kHalf + wave * 1024;
     const uint32_t ko = (uint32_t)(kt0 + t) * 64;
     glds16(p.Whi + woff[hf][0] + ko, base);
-    glds16(p.Whi + woff[hf][1] + ko, base + 8 * 1024);
+    if (NTW == 4 || hf == 0) glds16(p.Whi + woff[hf][1] + ko, base + 8 * 1024);      // (NTW = 3: W1 is rows 128..191 only)
   };
 
   // ---- fragment addresses (16x16x32 operands: lane (fr, fq) holds k = 8 fq .. 8 fq + 7 of row fr; hi chunk fq, lo chunk 4 + fq)
   const int fr = lane & 15, fq = lane >> 4;
-  int oa_hi[2][4], oa_lo[2][4], ow_hi[4], ow_lo[4];
+  int oa_hi[2][4], oa_lo[2][4], ow_hi[NTW], ow_lo[NTW];
 #pragma unroll
   for (int ra = 0; ra < 2; ++ra)
 #pragma unroll
@@ -98,20 +103,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
       oa_lo[ra][i] = grp * kRegion + frag_off(row, 4 + fq);
     }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wc & 1) * 64 + i * 16 + fr;
-    ow_hi[i] = (2 + (wc >> 1)) * kRegion + frag_off(row, fq);
-    ow_lo[i] = (2 + (wc >> 1)) * kRegion + frag_off(row, 4 + fq);
+  for (int i = 0; i < NTW; ++i) {
+    const int row = wc * 16 * NTW + i * 16 + fr;               // row of the W tile; rows 0-127 live in region W0, the rest in W1
+    ow_hi[i] = (2 + (row >> 7)) * kRegion + frag_off(row & 127, fq);
+    ow_lo[i] = (2 + (row >> 7)) * kRegion + frag_off(row & 127, 4 + fq);
   }
 
-  f32x4 acc[2][4][4];                         // [row half][mi][ni]
+  f32x4 acc[2][4][NTW];                       // [row half][mi][ni]
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[a][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  half8 ah[4], al[4], wh[4], wl[4];
+      for (int j = 0; j < NTW; ++j) acc[a][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  half8 ah[4], al[4], wh[NTW], wl[NTW];
 
 #define OVM_READ_A(RA, BASE)                                                           \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
@@ -119,13 +124,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     al[i] = *(const half8*)((BASE) + oa_lo[RA][i]);                                    \
   }
 #define OVM_READ_W(BASE)                                                               \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
+  _Pragma("unroll") for (int i = 0; i < NTW; ++i) {                                    \
     wh[i] = *(const half8*)((BASE) + ow_hi[i]);                                        \
     wl[i] = *(const half8*)((BASE) + ow_lo[i]);                                        \
   }
 #define OVM_QUAD(RA, CB)                                                               \
   __builtin_amdgcn_s_setprio(1);                                                       \
   _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                     \
+  if ((CB) * 2 + ni < NTW)                                                             \
   _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                   \
     f32x4 c_ = acc[RA][mi][(CB) * 2 + ni];                                             \
     c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[(CB) * 2 + ni], ah[mi], c_, 0, 0, 0); \
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 
   // ---- prologue: k-group 0 complete, W0 / W1 of k-group 1
   stage_a(0, 0); stage_a(0, 1); stage_w(0, 0); stage_w(0, 1);
-  if (nk > 1) { stage_w(1, 0); stage_w(1, 1); wait_vmcnt<4>(); } else { wait_vmcnt<0>(); }
+  if (nk > 1) { stage_w(1, 0); stage_w(1, 1); wait_vmcnt<WP>(); } else { wait_vmcnt<0>(); }
   OVM_BAR();
   if (grp == 1) OVM_BAR();                    // G1 runs one interval behind G0
 
@@ -167,11 +173,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     OVM_READ_A(1, base)                       /* Lb */                                 \
     if (t + 2 < nk) { stage_w(t + 2, 0); stage_w(t + 2, 1); }                          \
     __builtin_amdgcn_s_waitcnt(0xC07F);                                                \
-    if (grp == 1) { if (t + 2 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>(); }           \
+    if (grp == 1) { if (t + 2 < nk) wait_vmcnt<WP>(); else wait_vmcnt<0>(); }           \
     OVM_BAR();                                                                         \
     OVM_QUAD(1, 1)                            /* Cb */                                 \
     OVM_QUAD(1, 0)                                                                     \
-    if (grp == 0) { if (t + 2 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>(); }           \
+    if (grp == 0) { if (t + 2 < nk) wait_vmcnt<WP>(); else wait_vmcnt<0>(); }           \
     OVM_BAR();                                                                         \
   }
   int t2 = 0;
@@ -194,62 +200,84 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
   // image [hi 32 | lo 32 | hi 32 | lo 32] per row and instruction.
   constexpr int TLD = 68;                                      // padded row stride (floats)
   float* tile = (float*)smem + wave * (64 * TLD);
-  const int mb = m0 + grp * 128, nb = n0 + wc * 64;
-  bool vt_tile = false;
-  if (EPI == EPI_QKV && ksplit == 1) vt_tile = (nb / (p.N / 3)) == 2;   // wave-uniform: head blocks are 64 wide
+  const int mb = m0 + grp * 128, nb = n0 + wc * 16 * NTW;
+  // V^T destination per 16-column group (wave-uniform: head blocks are 64 wide and the Q | K | V boundaries multiples of 64). With
+  // NTW = 4 a wave's 64 columns are one head, so all four groups agree; with NTW = 3 a wave can straddle the K | V boundary.
+  bool vt[NTW];
+#pragma unroll
+  for (int ni = 0; ni < NTW; ++ni) vt[ni] = (EPI == EPI_QKV && ksplit == 1) ? ((nb + ni * 16) / (p.N / 3)) == 2 : false;
+  bool any_rm = false, any_vt = false;
+#pragma unroll
+  for (int ni = 0; ni < NTW; ++ni) { any_rm = any_rm || !vt[ni]; any_vt = any_vt || vt[ni]; }
 #pragma unroll
   for (int ra = 0; ra < 2; ++ra) {
-    if (!vt_tile) {
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) *(f32x4*)(tile + (mi * 16 + fr) * TLD + ni * 16 + fq * 4) = acc[ra][mi][ni];
-    } else {
-      // V^T tiles are staged TRANSPOSED ([d][token]): the store loop below reads a token per lane for one d at a time, which on the
-      // row-major image was 64 lanes at a stride of 68 floats = 8 lanes per bank (PMC r02: LDS conflict cycles 0.335 of the LDS
-      // instructions in the qkv GEMM against 0.13 in fc1, same main loop); transposed it is 64 consecutive floats.
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) tile[(ni * 16 + fq * 4 + e) * TLD + mi * 16 + fr] = acc[ra][mi][ni][e];
-    }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int mrow0 = mb + ra * 64;
-    if (!vt_tile) {
+    // ---- phase 1: the row-major groups (everything but V^T) share the staging tile [token row][column]
+    if (any_rm) {
+#pragma unroll
+      for (int ni = 0; ni < NTW; ++ni)
+        if (!vt[ni]) {
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) *(f32x4*)(tile + (mi * 16 + fr) * TLD + ni * 16 + fq * 4) = acc[ra][mi][ni];
+        }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const int col = (lane & 15) * 4;
+      bool mine = false;
+#pragma unroll
+      for (int ni = 0; ni < NTW; ++ni) mine = mine || ((col >> 4) == ni && !vt[ni]);
+      if (mine) {
 #pragma unroll 4
-      for (int it = 0; it < 16; ++it) {
-        const int row = it * 4 + (lane >> 4);
-        const f32x4 v = *(const f32x4*)(tile + row * TLD + col);
-        const int m = mrow0 + row, n = nb + col;
-        if (m < p.M) {
-          if (ksplit > 1) { if (n < p.N) *(f32x4*)(p.part + ((size_t)ks * p.M + m) * p.N + n) = v; }
-          else epilogue4<EPI>(p, m, n, v);
+        for (int it = 0; it < 16; ++it) {
+          const int row = it * 4 + (lane >> 4);
+          const f32x4 v = *(const f32x4*)(tile + row * TLD + col);
+          const int m = mrow0 + row, n = nb + col;
+          if (m < p.M) {
+            if (ksplit > 1) { if (n < p.N) *(f32x4*)(p.part + ((size_t)ks * p.M + m) * p.N + n) = v; }
+            else epilogue4<EPI>(p, m, n, v);
+          }
         }
       }
-    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ---- phase 2: V^T groups, staged TRANSPOSED ([d][token]) in the same tile (a wave that straddles the K | V boundary holds both
+    // kinds, and the two images overlap - hence two phases). The store loop reads a token per lane for one d at a time, which on a
+    // row-major image was 64 lanes at a stride of 68 floats = 8 lanes per bank (PMC r02: LDS conflict cycles 0.335 of the LDS
+    // instructions in the qkv GEMM against 0.13 in fc1, same main loop); transposed it is 64 consecutive floats.
+    if (EPI == EPI_QKV && any_vt) {
+#pragma unroll
+      for (int ni = 0; ni < NTW; ++ni)
+        if (vt[ni]) {
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[(ni * 16 + fq * 4 + e) * TLD + mi * 16 + fr] = acc[ra][mi][ni][e];
+        }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       // V^T [b][head][d][Tpad]: tokens are the contiguous axis, so lanes run along m (one 2-byte element each, 128 B per store)
       const int m = mrow0 + lane;
-      if (m < p.M) {
-        const int Dm = p.N / 3;
-        const int head = (nb - 2 * Dm) >> 6;
-        const int b = m / p.T, t = m - b * p.T;
-        const int tp = (t & ~15) | (t & 3) | ((t & 4) << 1) | ((t & 8) >> 1);
-        const size_t o0 = ((size_t)(b * p.heads + head) * 64) * p.Tpad + tp;
-        for (int d = 0; d < 64; ++d) {
-          float x = tile[d * TLD + lane];
-          if (p.bias) x += p.bias[nb + d];
-          half_t hh, ll; split_f16(x, hh, ll);
-          p.Vhi[o0 + (size_t)d * p.Tpad] = hh;
-          if (p.Vlo) p.Vlo[o0 + (size_t)d * p.Tpad] = ll;
+      const int Dm = p.N / 3;
+#pragma unroll
+      for (int ni = 0; ni < NTW; ++ni)
+        if (vt[ni] && m < p.M) {
+          const int f0 = nb + ni * 16 - 2 * Dm;                       // feature index of the group's first column inside V
+          const int head = f0 >> 6, d0 = f0 & 63;
+          const int b = m / p.T, t = m - b * p.T;
+          const int tp = (t & ~15) | (t & 3) | ((t & 4) << 1) | ((t & 8) >> 1);
+          const size_t o0 = ((size_t)(b * p.heads + head) * 64 + d0) * p.Tpad + tp;
+          for (int d = 0; d < 16; ++d) {
+            float x = tile[(ni * 16 + d) * TLD + lane];
+            if (p.bias) x += p.bias[nb + ni * 16 + d];
+            half_t hh, ll; split_f16(x, hh, ll);
+            p.Vhi[o0 + (size_t)d * p.Tpad] = hh;
+            if (p.Vlo) p.Vlo[o0 + (size_t)d * p.Tpad] = ll;
+          }
         }
-      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
   }
 #undef OVM_BAR
   if (STAMP && blockIdx.x == 0 && p.stamps) {
@@ -265,6 +293,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 }
 
 float* g_ws256 = nullptr; size_t g_ws256_cap = 0;
+int g_gemm256_n192 = 1;              // ovm_tune_set("gemm256_n192", 0): qkv on 256 x 256 tiles as in round 2
 
 template <int EPI>
 int launch256(const GemmParams& p, int want_split, hipStream_t s) {
@@ -310,6 +339,20 @@ int launch256(const GemmParams& p, int want_split, hipStream_t s) {
     }
   }
   q.main_tiles = tiles_m * tiles_n * q.ksplit;
+  // 256 x 192 tiles where they cost fewer rounds x tile size than 256 x 256 (ViT-L qkv at batch 1: 256 tiles x 3/4 against 192 x 1)
+  if (EPI == EPI_QKV && q.ksplit == 1 && g_gemm256_n192 && p.N % 192 == 0) {
+    const long t4 = (long)tiles_m * tiles_n, t3 = (long)tiles_m * (p.N / 192);
+    if (((t3 + 255) / 256) * 3 < ((t4 + 255) / 256) * 4) {
+      static bool attr3 = false;
+      if (!attr3) {
+        if (hipFuncSetAttribute((const void*)gemm256_kernel<EPI, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return OVM_ERR_HIP;
+        attr3 = true;
+      }
+      q.main_tiles = (int)t3;
+      hipLaunchKernelGGL((gemm256_kernel<EPI, 0, 3>), dim3(q.main_tiles + tail_blocks), dim3(512), smem, s, q);
+      return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+    }
+  }
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return OVM_ERR_HIP;
@@ -324,6 +367,8 @@ int launch256(const GemmParams& p, int want_split, hipStream_t s) {
 }
 
 }  // namespace
+
+void gemm256_set_n192(int v) { g_gemm256_n192 = v; }
 
 bool gemm256_supported(const GemmParams& p, int npass) {
   return npass == 3 && p.a_il && p.Alo == p.Ahi + 32 && p.Wlo == p.Whi + 32 && p.K % 32 == 0 && p.lda == 2 * p.K && p.N % 256 == 0;
