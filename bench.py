@@ -255,7 +255,7 @@ def main():
     # HBM-side bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass over this same command
     # (profiles/rNN/pmc_traffic_*.json documents the command and the gfx950 FETCH_SIZE correction; newest round first); null if none matches
     traffic = traffic_source = None
-    for tdir in ("r02", "r01"):
+    for tdir in ("r03", "r02", "r01"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", tdir, "pmc_traffic_f16x3_vitl14_T4097_b1.json")))
             wl = tj["workload"]

@@ -347,13 +347,20 @@ int ovm_g_topk(const float* scores, int32_t n, int32_t k, int32_t* out_idx, ovm_
  *   gemm_bm 0|128|256, gemm_stages 0 (auto: wave-specialised kernel up to 512 tiles, symmetric 2-slot kernel above) |2|3|5|6,
  *   gemm_splitk 0|1, gemm_tail 0|1 (leftover rows as dot-product workgroups), attn_waves 0 (auto)|4|8, attn_lds_pad bytes,
  *   gemm256 0|1 (256 x 256 two-wave-group kernel for qkv / fc1), op_gemm256 n (ovm_op_gemm on that kernel, n = split-K hint),
- *   attn_tail 0|1, glin_small_max_tiles (-1 = heuristic), glin_target_blocks, glin_max_ksplit, glin_stages 1|2, gbmm_tiled 0|1 */
+ *   attn_tail 0|1, glin_small_max_tiles (-1 = heuristic), glin_target_blocks, glin_max_ksplit, glin_stages 1|2, gbmm_tiled 0|1,
+ *   gemm256_n192 0|1 (qkv on 256 x 192 tiles where they fill the chip better; default 1), attn_q64 0|1 (the 4-wave x 64-query attention
+ *   kernel; default 0: measured slower), attn_pp 0|1 (two-wave-group attention kernel), msdeform_vec 0|1 (vectorised deformable sampling;
+ *   default 1), gdino_dec_chain 0|1 (GroundingDINO decoder layers as row-chain kernels; default 1; read when a plan is built),
+ *   gdino_branches 0|1. Values that select timing-only ablations with wrong results exist in -DOVM_DIAG builds only. */
 int ovm_tune_set(const char* key, int32_t value);
-/* diagnostic builds: device pointer for a named debug hook ("gemm256_stamps": u64 [8 waves][128] s_memtime stamps of workgroup 0) */
+/* diagnostic hooks: device pointer for a named debug hook ("gemm256_stamps": u64 [8 waves][128] s_memtime stamps of workgroup 0;
+ * "attn_stamps": -DOVM_DIAG builds only, OVM_ERR_UNSUPPORTED otherwise) */
 int ovm_debug_set_ptr(const char* key, void* ptr);
 
 /* --- introspection for tests: copy a named intermediate of the last forward into dst (device).
- * names: "tokens" [B*T][D] fp32, "p2" / "p3" / "p4". Returns the element count or a negative error. */
+ * names: "tokens" [B*T][D] fp32, "p2" / "p3" / "p4" (/ "p5"); "rpn_boxes" [B][R][4], "rpn_scores" [B][R], "rpn_counts" [B] (int32 bits) =
+ * the RPN's proposals after top-k / NMS of the last ovm_rpn_box_forward; "cube_head" [n][16] = the cube head's raw outputs of the
+ * last ovm_cube_forward (deltas 2, dims 3, pose 6-D, depth 1, uncertainty 1). Returns the element count or a negative error. */
 int64_t ovm_debug_copy(OvmHandle* h, const char* name, float* dst, int64_t capacity, ovm_stream_t stream);
 
 /* ---- evaluation ("next" row 1 of SURVEY.md 8f) ---------------------------------------------------------------------------
