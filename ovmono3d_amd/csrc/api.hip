@@ -325,6 +325,7 @@ struct ProfScope {
 };
 
 int g_use_gemm256 = 1;     // ovm_tune_set("gemm256", 0 | 1)
+int g_gemm256_ksplit = 0;  // ovm_tune_set("gemm256_ksplit", n)
 
 int gemm(OvmHandle* h, const GemmParams& p, int epi, int amode, hipStream_t s, int cat = -1) {
   ProfScope ps(h, cat, s);
@@ -335,6 +336,10 @@ int gemm(OvmHandle* h, const GemmParams& p, int epi, int amode, hipStream_t s, i
   if (g_use_gemm256 && amode == A_ROWMAJOR && gemm256_supported(p, h->npass) &&
       (long)((p.M + 255) / 256) * (p.N / 256) >= 192 && (epi == EPI_STORE || epi == EPI_RESID || epi == EPI_GELU || epi == EPI_QKV))
     return launch_gemm256(p, epi, 1, s);
+  // experiment knob (ovm_tune_set "gemm256_ksplit"): the long-K contractions with too few 256-wide tiles (fc2 at batch 1: 64 tiles,
+  // K = 4096) as k-slices of 256 x 256 tiles + a reduce pass - half the operand fetch of 128 x 128 tiles
+  if (g_gemm256_ksplit > 1 && amode == A_ROWMAJOR && gemm256_supported(p, h->npass) && epi == EPI_RESID && p.K >= 2048 && !p.row_map)
+    return launch_gemm256(p, epi, g_gemm256_ksplit, s);
   return launch_gemm(p, h->npass, epi, amode, s);
 }
 
@@ -360,7 +365,7 @@ void fill_meta(OvmHandle* h, const OvmImage* images, int B) {
 
 }  // namespace
 
-namespace ovm { void set_use_gemm256(int v) { g_use_gemm256 = v; } }
+namespace ovm { void set_use_gemm256(int v) { g_use_gemm256 = v; } void set_gemm256_ksplit(int v) { g_gemm256_ksplit = v; } }
 
 extern "C" {
 

@@ -319,7 +319,7 @@ int launch256(const GemmParams& p, int want_split, hipStream_t s) {
   const int tiles_m = (q.M + 255) / 256, tiles_n = (p.N + 255) / 256;
   const int nk = p.K / 32;
   int ks = want_split;
-  if (ks > 1 && tail_blocks == 0 && p.N % 4 == 0) {
+  if (ks > 1 && p.N % 4 == 0) {                           // (leftover rows keep their dot-product workgroups: those run the whole K and store final values)
     if (ks > nk / 8) ks = nk / 8;
     if (ks > 1) {
       const int chunk = (nk + ks - 1) / ks;

@@ -56,7 +56,7 @@ struct Tmp {
 };
 }  // namespace
 
-namespace ovm { void set_use_gemm256(int v); void set_gdino_branches(int v); void msdeform_set_vec(int v); void set_gdino_dec_chain(int v); void gemm256_set_n192(int v); }
+namespace ovm { void set_use_gemm256(int v); void set_gdino_branches(int v); void msdeform_set_vec(int v); void set_gdino_dec_chain(int v); void gemm256_set_n192(int v); void set_gemm256_ksplit(int v); }
 
 extern "C" {
 
@@ -211,6 +211,7 @@ int ovm_tune_set(const char* key, int32_t value) {
   if (!strcmp(key, "glin_stages")) { gemm_small_set_stages(value); return OVM_OK; }
   if (!strcmp(key, "glin_wpe")) { gemm_small_set_wpe(value); return OVM_OK; }
   if (!strcmp(key, "glin_max_ksplit")) { gemm_small_set(-1, value); return OVM_OK; }
+  if (!strcmp(key, "gemm256_ksplit")) { ovm::set_gemm256_ksplit(value); return OVM_OK; }
   if (!strcmp(key, "gemm256_n192")) { ovm::gemm256_set_n192(value); return OVM_OK; }     // qkv: 256 x 192 tiles when they fill the chip better (default 1)
   if (!strcmp(key, "gemm256")) { ovm::set_use_gemm256(value); return OVM_OK; }          // engine: 256 x 256 kernel for qkv / fc1 (default 1)
   if (!strcmp(key, "op_gemm256")) { g_op_gemm256 = value; return OVM_OK; }

@@ -314,7 +314,7 @@ def test_gdino_glue_shapes_and_paths(device, nq, ncat, crowd):
 
 
 @pytest.mark.parametrize("M,N,K,ksplit", [(256, 256, 64, 1), (300, 512, 96, 1), (4097, 768, 256, 1), (1024, 256, 1024, 4), (700, 512, 2048, 8),
-                                          (512, 256, 32, 1)])
+                                          (512, 256, 32, 1), (4097, 512, 2048, 4)])       # last: split-K together with a leftover row
 def test_gemm256_two_wave_group_kernel(device, M, N, K, ksplit):
     """The 256 x 256 kernel (gemm256.hip: two wave groups ping-ponging LOAD / COMPUTE segments, re-staged half-tiles, counted
     vmcnt across raw barriers) through ovm_op_gemm: exact on small integers with an asymmetric W (fragment / quadrant maps),
