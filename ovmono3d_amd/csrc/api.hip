@@ -79,6 +79,7 @@ struct OvmHandle {
   Split PA, HN, AO, F1, Q, Kx, Vt, DT, DT4, DF, CT, CT4a, CT4b;
   float *dtok = nullptr, *FUS = nullptr;
   Split RF, H1, H2; float* HO = nullptr; int lastN = 0;
+  float* attn_tail_ws = nullptr; int* attn_tail_cnt = nullptr;     // attention's leftover-query partials / arrival counters (attn_tail.hpp)
   float* rec = nullptr; int* keep = nullptr;
   int *d_bidx = nullptr;
   ImageDesc* d_imgs = nullptr; ImageMeta* d_meta = nullptr;
@@ -801,6 +802,8 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
   if ((r = salloc(h, &h->Q, MT * D))) return r;
   if ((r = salloc(h, &h->Kx, MT * D))) return r;
   if ((r = salloc(h, &h->Vt, (size_t)B * D * h->Tpad, true))) return r;
+  if ((r = dalloc(h, &h->attn_tail_ws, attn_tail_ws_floats(B, c.heads)))) return r;
+  if ((r = dalloc(h, &h->attn_tail_cnt, (size_t)B * c.heads * 8, true))) return r;
   if ((r = salloc(h, &h->DT, MP * D))) return r;
   if ((r = salloc(h, &h->DT4, (size_t)B * (G / 2) * (G / 2) * D))) return r;
   if (h->has_dfuse) {
@@ -985,6 +988,7 @@ int ovm_backbone_forward(OvmHandle* h, const OvmImage* images, int32_t B, const 
       a.Qhi = h->Q.hi; a.Qlo = h->Q.lo; a.Khi = h->Kx.hi; a.Klo = h->Kx.lo; a.Vhi = h->Vt.hi; a.Vlo = h->Vt.lo;
       a.Ohi = h->AO.hi; a.Olo = h->AO.lo; a.ldo = am * D; a.o_il = il; a.B = B; a.heads = c.heads; a.T = T; a.Tpad = h->Tpad;
       a.corun = h->corun ? 1 : 0;
+      a.tail_ws = h->attn_tail_ws; a.tail_cnt = h->attn_tail_cnt;     // leftover queries (T = 4097: one per head) split over the keys
       { ProfScope ps(h, OVM_PROF_ATTN, s); KCHECK(h, launch_attention(a, h->npass, s)); }
     }
     {

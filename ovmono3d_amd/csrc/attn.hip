@@ -60,7 +60,7 @@ constexpr float kPShift = 14.0f;       // log2 of the scale the main kernel carr
 template <int NPASS, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if ((int)blockIdx.x >= p.main_blocks) { attn_tail_body<NPASS>(p, (int)blockIdx.x - p.main_blocks, smem); return; }
+  if ((int)blockIdx.x >= p.main_blocks) { attn_tail_any<NPASS>(p, (int)blockIdx.x - p.main_blocks, smem); return; }
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   // diagnostic (ovm_debug_set_ptr "attn_stamps" with the lock-step kernel): every workgroup records its start / end s_memtime and its XCC id
   const unsigned long long t_wg0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -366,7 +366,7 @@ template <int NPASS, int STAMP = 0>
 __global__ __launch_bounds__(512, 1) void attn_pp_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = 8, RD = 4;
-  if ((int)blockIdx.x >= p.main_blocks) { attn_tail_body<NPASS>(p, (int)blockIdx.x - p.main_blocks, smem); return; }
+  if ((int)blockIdx.x >= p.main_blocks) { attn_tail_any<NPASS>(p, (int)blockIdx.x - p.main_blocks, smem); return; }
   static_assert(NPASS == 3, "split precision only");
   constexpr int PART = 64 * 128;
   constexpr int SLOT = 2 * PART;
@@ -642,8 +642,35 @@ __global__ __launch_bounds__(512, 1) void attn_pp_kernel(const AttnParams p) {
   }
 }
 
+// The partials of a (head, leftover query) are combined by a tiny follow-up kernel (launch_attention enqueues it right behind the
+// attention kernel): the kernel boundary is the release / acquire. An in-kernel "last arriver combines" needs a device-scope fence per
+// workgroup, and on this chip that is an L2 write-back of everything the main workgroups have just stored - measured: no faster
+// than the unsplit tail.
+__global__ __launch_bounds__(64) void attn_tail_combine_kernel(const AttnParams p) {
+  const int tq = blockIdx.x, tid = threadIdx.x;
+  const int ntail = p.T - p.Tq;
+  const int bh = tq / ntail, q = p.Tq + (tq - bh * ntail);
+  const int b = bh / p.heads, head = bh - b * p.heads;
+  const float* recs = p.tail_ws + (size_t)tq * kTailSplit * kTailRec;
+  float M = -1e30f;
+  for (int i = 0; i < kTailSplit; ++i) M = fmaxf(M, recs[i * kTailRec]);
+  float Ltot = 0.f, o = 0.f;
+  for (int i = 0; i < kTailSplit; ++i) {          // fixed order: deterministic
+    const float w = __builtin_amdgcn_exp2f(recs[i * kTailRec] - M);
+    Ltot = fmaf(recs[i * kTailRec + 1], w, Ltot);
+    o = fmaf(recs[i * kTailRec + 4 + tid], w, o);
+  }
+  half_t hh, ll; split_f16(o / Ltot, hh, ll);
+  const size_t oo = ((size_t)b * p.T + q) * p.ldo + (p.o_il ? il_col(head * 64 + tid) : head * 64 + tid);
+  p.Ohi[oo] = hh;
+  if (p.Olo) p.Olo[oo] = ll;
+}
+
 static int g_attn_tail = 1;
 void attn_set_tail_rows(int on) { g_attn_tail = on; }
+static int g_attn_tail_split = 1;   // leftover queries split over the keys when the caller provides a workspace (ovm_tune_set "attn_tail_split" 0: one workgroup each)
+void attn_set_tail_split(int on) { g_attn_tail_split = on; }
+size_t attn_tail_ws_floats(int B, int heads) { return (size_t)B * heads * 8 * kTailSplit * kTailRec; }
 static int g_attn_lds_pad = 0;      // experiment: extra dynamic LDS per workgroup (lowers workgroups per CU)
 void attn_set_lds_pad(int v) { g_attn_lds_pad = v; }
 static unsigned long long* g_attn_stamps = nullptr;
@@ -681,15 +708,21 @@ int launch_attention(const AttnParams& p, int npass, hipStream_t s) {
   pm.Tq = p.T;
   if (g_attn_tail && tail > 0 && tail <= 8 && p.T > qpb && (p.Tpad + 16) * 4 <= 2 * 2 * 64 * 128) {
     pm.Tq = p.T - tail;                            // leftover queries ride along as extra workgroups
-    tail_blocks = tail * p.heads * p.B;
-  }
+    if (!g_attn_tail_split) { pm.tail_ws = nullptr; pm.tail_cnt = nullptr; }
+    // with a workspace from the caller: kTailSplit workgroups per leftover query, each over a run of key tiles (attn_tail.hpp)
+    tail_blocks = tail * p.heads * p.B * (pm.tail_ws ? kTailSplit : 1);
+  } else { pm.tail_ws = nullptr; pm.tail_cnt = nullptr; }
   const int nqb = (pm.Tq + qpb - 1) / qpb;
   pm.main_blocks = nqb * p.heads * p.B;
   const dim3 grid(pm.main_blocks + tail_blocks), block(64 * nw);
   const int pad = g_attn_lds_pad;                  // experiment knob; the 3-slot rings (96 KB) already keep a workgroup alone on its CU
   if (npass == 3) {
     const int smem = OVM_ATTN_RD * 4 * 64 * 128 + pad;
-    if (nw == 8 && g_attn_q64 && !g_attn_pp) return launch_attention64(pm, tail_blocks, s);
+    if (nw == 8 && g_attn_q64 && !g_attn_pp) {
+      const int r64 = launch_attention64(pm, tail_blocks, s);
+      if (r64 == OVM_OK && tail_blocks > 0 && pm.tail_ws) hipLaunchKernelGGL(attn_tail_combine_kernel, dim3(tail * p.heads * p.B), dim3(64), 0, s, pm);
+      return r64;
+    }
     if (nw == 8 && g_attn_pp) {
       constexpr int smem_pp = 2 * 4 * 2 * 64 * 128;        // two 4-slot rings of hi + lo tiles = 128 KiB
       static bool setpp = false;
@@ -716,6 +749,7 @@ int launch_attention(const AttnParams& p, int npass, hipStream_t s) {
     }
   } else if (nw == 8) hipLaunchKernelGGL((attn_kernel<1, 8>), grid, block, OVM_ATTN_RD * 2 * 64 * 128, s, pm);
   else hipLaunchKernelGGL((attn_kernel<1, 4>), grid, block, OVM_ATTN_RD * 2 * 64 * 128, s, pm);
+  if (tail_blocks > 0 && pm.tail_ws) hipLaunchKernelGGL(attn_tail_combine_kernel, dim3(tail * p.heads * p.B), dim3(64), 0, s, pm);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 

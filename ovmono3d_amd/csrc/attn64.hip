@@ -42,7 +42,7 @@ constexpr float kPShift = 14.0f;
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn64_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if ((int)blockIdx.x >= p.main_blocks) { attn_tail_body<3>(p, (int)blockIdx.x - p.main_blocks, smem); return; }
+  if ((int)blockIdx.x >= p.main_blocks) { attn_tail_any<3>(p, (int)blockIdx.x - p.main_blocks, smem); return; }
   constexpr int NW = 4, QW = 64;                       // waves per workgroup, queries per wave
   constexpr int PART = 64 * 128;                       // 64 rows x 128 B
   constexpr int SLOT = PART * 2;                       // hi + lo

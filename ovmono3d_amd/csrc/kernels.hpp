@@ -27,6 +27,9 @@ struct AttnParams {
   int Tq, main_blocks;                               // set by the launcher: queries / workgroups of the tiled part
   int prio_mode;                                     // experiment knob of the two-wave-group kernel (ovm_tune_set "attn_prio")
   unsigned long long* stamps;                        // diagnostic build of the two-wave-group kernel: s_memtime per barrier, [8 waves][128]
+  // leftover queries split over the keys (attn_tail.hpp): [B * heads * leftover][kTailSplit][68] floats and one counter per
+  // (batch, head, leftover query), zero between launches; null = one workgroup per leftover query (rounds 1-2)
+  float* tail_ws; int* tail_cnt;
 };
 
 constexpr int kMaxLevels = 4;   // pyramid levels: 3 (scales 2, 1, 0.5 - the DINOv2 tower) or 4 (4, 2, 1, 0.5 - CLIP / ViTDet style)
@@ -81,6 +84,9 @@ int launch_attention(const AttnParams& p, int npass, hipStream_t s);
 // attn64.hip: the 4-wave x 64-query form of the split-precision kernel (pm: Tq / main_blocks already set by launch_attention)
 int launch_attention64(const AttnParams& pm, int tail_blocks, hipStream_t s);
 void attn_set_q64(int v);
+void attn_set_tail_split(int on);
+// floats of AttnParams::tail_ws for up to 8 leftover queries per (batch, head); tail_cnt needs B * heads * 8 ints, zero-initialised once
+size_t attn_tail_ws_floats(int B, int heads);
 void attn_set_tail_rows(int on);
 void attn_set_lds_pad(int v);
 void attn_set_waves(int v);

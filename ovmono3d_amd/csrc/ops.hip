@@ -131,6 +131,8 @@ int ovm_op_attention(const float* qkv, int32_t B, int32_t T, int32_t heads, floa
   AttnParams a; memset(&a, 0, sizeof(a));
   a.Qhi = Qh; a.Qlo = Ql; a.Khi = Kh; a.Klo = Kl; a.Vhi = Vh; a.Vlo = Vl; a.Ohi = Oh; a.Olo = Ol; a.ldo = D;
   a.B = B; a.heads = heads; a.T = T; a.Tpad = Tpad;
+  a.tail_ws = tmp.get<float>(attn_tail_ws_floats(B, heads)); a.tail_cnt = tmp.get<int>((size_t)B * heads * 8, true);
+  if (!a.tail_ws || !a.tail_cnt) return OVM_ERR_HIP;
   int r = launch_attention(a, precision, s);
   if (r) return r;
   hipLaunchKernelGGL(join_kernel, dim3((unsigned)((nqk + 255) / 256)), dim3(256), 0, s, Oh, Ol, (int64_t)nqk, out);
@@ -205,6 +207,7 @@ int ovm_tune_set(const char* key, int32_t value) {
   if (!strcmp(key, "attn_prio")) { attn_set_prio(value); return OVM_OK; }
   if (!strcmp(key, "attn_lds_pad")) { attn_set_lds_pad(value); return OVM_OK; }
   if (!strcmp(key, "attn_tail")) { attn_set_tail_rows(value); return OVM_OK; }
+  if (!strcmp(key, "attn_tail_split")) { attn_set_tail_split(value); return OVM_OK; }
   if (!strcmp(key, "glin_small_max_tiles")) { glinear_set_small_max_tiles(value); return OVM_OK; }
   if (!strcmp(key, "glin_target_blocks")) { gemm_small_set(value, -1); return OVM_OK; }
   if (!strcmp(key, "gbmm_tiled")) { gbmm_set_tiled(value); return OVM_OK; }
