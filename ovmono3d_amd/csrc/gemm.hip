@@ -26,7 +26,8 @@ static int launch_one(const GemmParams& p, hipStream_t s) {
     // leftover rows (the cls token of the 4097-token canvas) ride along as extra dot-product workgroups
     q.tail_begin = p.M - tail;
     q.M = q.tail_begin;
-    const int waves = BM / 32;
+    const int waves = gemm_tail_waves(p.N, BM / 32);
+    q.tail_waves = waves;
     tail_blocks = tail * ((p.N + 4 * waves - 1) / (4 * waves));
   }
   const int tiles_m = (q.M + BM - 1) / BM;
@@ -84,7 +85,8 @@ static int launch_ws(const GemmParams& p, hipStream_t s) {
   if (q.ksplit == 1 && g_tail_rows && tail > 0 && tail <= 8 && p.M > 128 && p.K % 64 == 0) {
     q.tail_begin = p.M - tail;
     q.M = q.tail_begin;
-    tail_blocks = tail * ((p.N + 4 * 8 - 1) / (4 * 8));        // 8 waves per workgroup, 4 columns per wave
+    q.tail_waves = gemm_tail_waves(p.N, 8);                    // of the 8 waves per workgroup; 4 columns per wave
+    tail_blocks = tail * ((p.N + 4 * q.tail_waves - 1) / (4 * q.tail_waves));
   }
   const int tiles_m = (q.M + 127) / 128;
   const int tiles_n = (p.N + 127) / 128;

@@ -63,6 +63,7 @@ struct GemmParams {
   // set by the launcher: workgroups [0, main_tiles) run MFMA tiles over rows [0, tail_begin); workgroups beyond
   // them compute the leftover rows [tail_begin, M) with the dot-product body (see gemm_tail_body)
   int main_tiles, tail_begin, M_total;
+  int tail_waves;                                 // waves per leftover-row workgroup that work (0 = all of them)
 };
 
 template <int BK> __device__ __forceinline__ int swz_slot(int row, int chunk);
@@ -633,8 +634,12 @@ __global__ void splitk_epilogue_kernel(const GemmParams p) {
 template <int NPASS, int EPI, int AMODE, bool AIL>
 __device__ __forceinline__ void gemm_tail_body(const GemmParams& p, int tb) {
   // tb = tail workgroup index; every wave computes 4 consecutive columns of one leftover row
+  // Only the first p.tail_waves waves of a workgroup work (set by the launcher, gemm_tail_waves): the leftover row needs EVERY row of W,
+  // and a second round of a few fat workgroups reads it through a few CUs (fc2 at ViT-L: 32 workgroups x 512 KB = +7.9 us on a 91-us
+  // launch); thin workgroups spread the same bytes over >= 128 CUs.
   const int lane = threadIdx.x & 63;
-  const int waves = blockDim.x >> 6;
+  const int waves = p.tail_waves > 0 ? p.tail_waves : (int)(blockDim.x >> 6);
+  if ((int)(threadIdx.x >> 6) >= waves) return;
   const int groups_per_row = (p.N + 4 * waves - 1) / (4 * waves);
   const int row = tb / groups_per_row;
   const int n = ((tb - row * groups_per_row) * waves + (threadIdx.x >> 6)) * 4;
@@ -643,6 +648,7 @@ __device__ __forceinline__ void gemm_tail_body(const GemmParams& p, int tb) {
   constexpr bool AI = AIL && NPASS == 3, WI = NPASS == 3;
   const uint32_t arow = a_row_off<AMODE, AI>(p, m);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2                                   // two iterations' loads in flight: the leftover-row round is latency, not bandwidth
   for (int k0 = lane * 8; k0 < p.K; k0 += 512) {
     const uint32_t ao = arow + a_k_off<AMODE, AI>(p, k0 & ~63) + (AI ? ((k0 & 32) * 2 + (k0 & 31)) : (k0 & 63));
     const half8 ah = *(const half8*)(p.Ahi + ao);
@@ -679,6 +685,8 @@ __device__ __forceinline__ void gemm_tail_body(const GemmParams& p, int tb) {
   }
 }
 
+// waves per leftover-row workgroup (4 columns each) such that a row's columns spread over >= 128 workgroups where N allows
+inline int gemm_tail_waves(int N, int max_waves) { int w = max_waves; while (w > 1 && (N + 4 * w - 1) / (4 * w) < 128) w >>= 1; return w; }
 // Host launcher (defined in gemm.hip). npass in {1,3}.
 int launch_gemm(const GemmParams& p, int npass, int epi, int amode, hipStream_t stream);
 // false when an operand offset of this launch would not fit the kernels' 32-bit element offsets (launchers then return OVM_ERR_CAPACITY)

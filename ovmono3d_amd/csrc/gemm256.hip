@@ -314,7 +314,8 @@ int launch256(const GemmParams& p, int want_split, hipStream_t s) {
   const int tail = p.M % 256;
   if (tail > 0 && tail <= 8 && p.M > 256) {             // leftover rows (the cls token): dot-product workgroups of the same launch
     q.tail_begin = p.M - tail; q.M = q.tail_begin;
-    tail_blocks = tail * ((p.N + 4 * 8 - 1) / (4 * 8));
+    q.tail_waves = gemm_tail_waves(p.N, 8);
+    tail_blocks = tail * ((p.N + 4 * q.tail_waves - 1) / (4 * q.tail_waves));
   }
   const int tiles_m = (q.M + 255) / 256, tiles_n = (p.N + 255) / 256;
   const int nk = p.K / 32;
