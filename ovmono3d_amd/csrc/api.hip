@@ -80,6 +80,8 @@ struct OvmHandle {
   float *dtok = nullptr, *FUS = nullptr;
   Split RF, H1, H2; float* HO = nullptr; int lastN = 0;
   float* attn_tail_ws = nullptr; int* attn_tail_cnt = nullptr;     // attention's leftover-query partials / arrival counters (attn_tail.hpp)
+  float* splitk_ws = nullptr; size_t splitk_cap = 0;               // split-K partials of this handle's thin GEMMs (two handles on two streams
+                                                                   // must not share the launcher's process-global, re-sizable workspace)
   float* rec = nullptr; int* keep = nullptr;
   int *d_bidx = nullptr;
   ImageDesc* d_imgs = nullptr; ImageMeta* d_meta = nullptr;
@@ -328,8 +330,10 @@ struct ProfScope {
 int g_use_gemm256 = 1;     // ovm_tune_set("gemm256", 0 | 1)
 int g_gemm256_ksplit = 0;  // ovm_tune_set("gemm256_ksplit", n)
 
-int gemm(OvmHandle* h, const GemmParams& p, int epi, int amode, hipStream_t s, int cat = -1) {
+int gemm(OvmHandle* h, const GemmParams& p_in, int epi, int amode, hipStream_t s, int cat = -1) {
   ProfScope ps(h, cat, s);
+  GemmParams p = p_in;
+  if (!p.part_ws && h->splitk_ws) { p.part_ws = h->splitk_ws; p.part_cap = h->splitk_cap; }
   // the large block contractions (qkv, fc1: >= 2048 rows and >= 3072 columns -> at least 192 tiles of 256 x 256) go to the
   // two-wave-group 256 x 256 kernel; everything else keeps the 128 x 128 kernels
   // (at batch >= 4 the N = D contractions - proj, fc2 - reach that tile count too: 128 x 128 tiles fetch twice the operand bytes
@@ -367,6 +371,8 @@ void fill_meta(OvmHandle* h, const OvmImage* images, int B) {
 }  // namespace
 
 namespace ovm { void set_use_gemm256(int v) { g_use_gemm256 = v; } void set_gemm256_ksplit(int v) { g_gemm256_ksplit = v; } }
+
+static int backbone_launches(OvmHandle* h, int B, const float* prompt_depth, int depth_h, int depth_w, hipStream_t s);
 
 extern "C" {
 
@@ -802,6 +808,8 @@ int ovm_create(const OvmConfig* cfg, const OvmTensor* weights, int32_t n_weights
   if ((r = salloc(h, &h->Q, MT * D))) return r;
   if ((r = salloc(h, &h->Kx, MT * D))) return r;
   if ((r = salloc(h, &h->Vt, (size_t)B * D * h->Tpad, true))) return r;
+  h->splitk_cap = (size_t)112 << 20;     // split-K is only taken for <= 96 tiles of 128 x 128 with <= 16 slices: <= 100.7 MB of fp32 partials
+  { char* q = nullptr; if ((r = dalloc(h, &q, h->splitk_cap))) return r; h->splitk_ws = (float*)q; }
   if ((r = dalloc(h, &h->attn_tail_ws, attn_tail_ws_floats(B, c.heads)))) return r;
   if ((r = dalloc(h, &h->attn_tail_cnt, (size_t)B * c.heads * 8, true))) return r;
   if ((r = salloc(h, &h->DT, MP * D))) return r;
@@ -912,17 +920,30 @@ int ovm_backbone_forward(OvmHandle* h, const OvmImage* images, int32_t B, const 
       h->err = "image larger than SQUARE_PAD canvas"; return OVM_ERR_SHAPE;
     }
   HCHECK(h, hipSetDevice(h->device));
-  const int D = h->D, G = h->G, G2 = h->G2, T = h->T, L = c.depth;
   fill_meta(h, images, B);
   HCHECK(h, hipMemcpyAsync(h->d_imgs, h->h_imgs, sizeof(ImageDesc) * B, hipMemcpyHostToDevice, s));
   HCHECK(h, hipMemcpyAsync(h->d_meta, h->h_meta, sizeof(ImageMeta) * B, hipMemcpyHostToDevice, s));
   h->lastB = B;
-  // ---- patch embed (+ preprocess) ----
   if (prompt_depth && c.tower != OVM_TOWER_DINOV2) {
     // detectron2's SimpleFeaturePyramid.forward(x) takes no depth; the fork's RCNN3D passes one to every backbone and
     // would raise a TypeError here: refuse rather than silently drop it
     h->err = "prompt_depth is only defined for the DINOv2 tower (depth_fusion, dino.py:91-105)"; return OVM_ERR_INVALID;
   }
+  if (prompt_depth && !h->has_dfuse) { h->err = "prompt_depth given but depth_fusion weights absent / disabled"; return OVM_ERR_INVALID; }
+  const int rr = backbone_launches(h, B, prompt_depth, depth_h, depth_w, s);
+  if (rr) return rr;
+  const int C = h->C;
+  float* outs[3] = {p2, p3, p4};
+  for (int l = 0; l < 3; ++l)
+    if (outs[l]) HCHECK(h, hipMemcpyAsync(outs[l], h->lv[l].p, (size_t)B * h->lv[l].side * h->lv[l].side * C * 4, hipMemcpyDeviceToDevice, s));
+  return OVM_OK;
+}
+
+// every kernel launch of the backbone (patch embed .. pyramid), on stream s, shapes fixed by (B, canvas)
+static int backbone_launches(OvmHandle* h, int B, const float* prompt_depth, int depth_h, int depth_w, hipStream_t s) {
+  const OvmConfig& c = h->cfg;
+  const int D = h->D, G = h->G, G2 = h->G2, T = h->T, L = c.depth;
+  // ---- patch embed (+ preprocess) ----
   KCHECK(h, launch_patch_gather(h->d_imgs, B, G, h->patch, h->Kpe, c.pixel_mean, c.pixel_std, h->PA.hi, h->PA.lo, s));
   if (!h->sam) KCHECK(h, launch_cls_init(h->X, h->cls, h->pos, B, T, D, s));       // SAM: no class token (T = G^2)
   {
@@ -1011,7 +1032,6 @@ int ovm_backbone_forward(OvmHandle* h, const OvmImage* images, int32_t B, const 
   }
   // ---- depth fusion at the last block output (reference dino.py:91-105) ----
   if (prompt_depth) {
-    if (!h->has_dfuse) { h->err = "prompt_depth given but depth_fusion weights absent / disabled"; return OVM_ERR_INVALID; }
     KCHECK(h, launch_depth_resize(prompt_depth, B, depth_h, depth_w, G, h->dtok, s));
     KCHECK(h, launch_tokens_cast(h->X, B, T, G2, D, D + 64, h->dtok, h->DF.hi, h->DF.lo, s));
     GemmParams p = gp_base(h->DF, D + 64, h->dfuse, B * G2);
@@ -1036,10 +1056,6 @@ int ovm_backbone_forward(OvmHandle* h, const OvmImage* images, int32_t B, const 
     KCHECK(h, launch_maxpool2(h->DT.hi, h->DT.lo, B, G, D, h->DT4.hi, h->DT4.lo, s));
     KCHECK(h, sfp_branch(h, h->DT4, D, B, h->lv[li++], s));
   }
-  const int C = h->C;
-  float* outs[3] = {p2, p3, p4};
-  for (int l = 0; l < 3; ++l)
-    if (outs[l]) HCHECK(h, hipMemcpyAsync(outs[l], h->lv[l].p, (size_t)B * h->lv[l].side * h->lv[l].side * C * 4, hipMemcpyDeviceToDevice, s));
   return OVM_OK;
 }
 

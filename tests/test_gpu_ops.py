@@ -423,6 +423,36 @@ def test_attention_64_queries_per_wave_kernel_is_bit_identical(device, B, T, hea
         assert_close(a[:, T - tail:], b[:, T - tail:], 2e-6, "leftover-query rows")
 
 
+@pytest.mark.parametrize("B,T,heads", [(1, 4097, 16), (2, 261, 3), (1, 513, 2), (3, 1030, 1)])
+def test_attention_leftover_queries_split_over_keys(device, B, T, heads):
+    """The leftover queries of a launch (T = 4097: one per head; up to 8) are computed by 16 workgroups per query over runs of key tiles
+    + a combine kernel (attn_tail.hpp; round 3: the one-workgroup form cost a quarter of the ViT-L launch), against the one-workgroup
+    form (ovm_tune_set attn_tail_split = 0): tiled rows identical, leftover rows equal to fp32 rounding (the partial softmax states are
+    merged in a fixed order: repeated launches agree bit for bit), both fp32-class against fp64. Cases: 1, 5, 1 and 6 leftover queries."""
+    g = torch.Generator().manual_seed(T * 3 + heads)
+    qkv = (torch.randn(B * T, 3 * heads * 64, generator=g) * 1.5).to(device)
+    L = _lib()
+    outs = {}
+    try:
+        for split in (0, 1, 1):
+            assert L.ovm_tune_set(b"attn_tail_split", split) == 0
+            out = torch.full((B * T, heads * 64), float("nan"), device=device)
+            assert L.ovm_op_attention(qkv.data_ptr(), B, T, heads, out.data_ptr(), 3, _stream()) == 0
+            torch.cuda.synchronize()
+            outs.setdefault(split, []).append(out)
+    finally:
+        L.ovm_tune_set(b"attn_tail_split", 1)
+    tail = T % 256
+    assert 0 < tail <= 8
+    ref = _attn_ref(qkv.cpu(), B, T, heads)
+    assert_close(outs[1][0], ref, 5e-6, "split leftover queries vs fp64")
+    assert torch.equal(outs[1][0], outs[1][1])
+    a, b = outs[0][0].view(B, T, -1), outs[1][0].view(B, T, -1)
+    assert torch.equal(a[:, :T - tail], b[:, :T - tail])
+    assert_close(b[:, T - tail:], a[:, T - tail:], 2e-6, "leftover rows: split vs one workgroup")
+    assert_close(b[:, T - tail:], ref.view(B, T, -1)[:, T - tail:].to(device), 5e-6, "leftover rows vs fp64")
+
+
 @pytest.mark.parametrize("kernel", ["ws128", "gemm256"])
 def test_gemm_32bit_offset_boundary(device, kernel):
     """The GEMM kernels address their operands with 32-bit element offsets (gemm.hpp a_row_offset, gemm256.hip aoff). The
