@@ -290,6 +290,56 @@ __global__ __launch_bounds__(256) void groupnorm_kernel(const float* __restrict_
   }
 }
 
+// The same statistics with the group's slice held in registers: the neck's largest level (67 x 67 x 256 at a 532 x 532 image, 32 groups
+// of 8 channels) is 8,978 float4 per group - one workgroup of 1,024 threads reads each once (9 independent 16-byte loads per thread in
+// flight instead of three dependent strided passes of 140 iterations: 98.6 -> ~10 us per launch in the detector's trace), then mean,
+// centred sum of squares and the normalisation run on registers. Same two-pass formula; the order of the partial sums differs.
+constexpr int kGnMaxV = 12;
+__global__ __launch_bounds__(1024) void groupnorm_reg_kernel(const float* __restrict__ x, int HW, int Cc, int groups, const float* __restrict__ g,
+                                                             const float* __restrict__ b, float eps, float* __restrict__ y) {
+  __shared__ float red[32];
+  const int grp = blockIdx.x, bz = blockIdx.y, cpg = Cc / groups, q4 = cpg >> 2, n4 = HW * q4;
+  const float* xb = x + (size_t)bz * HW * Cc + (size_t)grp * cpg; float* yb = y + (size_t)bz * HW * Cc + (size_t)grp * cpg;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  f32x4 v[kGnMaxV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < kGnMaxV; ++j) {
+    const int i = tid + j * 1024;
+    v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (i < n4) { v[j] = *(const f32x4*)(xb + (size_t)(i / q4) * Cc + (i % q4) * 4); s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]); }
+  }
+  s = wave_sum(s); if (lane == 0) red[wave] = s; __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) tot += red[w];
+  const float mean = tot / (float)(n4 * 4);
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < kGnMaxV; ++j)
+    if (tid + j * 1024 < n4) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float d = v[j][r] - mean; q += d * d; }
+    }
+  q = wave_sum(q); if (lane == 0) red[16 + wave] = q; __syncthreads();
+  float qt = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) qt += red[16 + w];
+  const float rstd = 1.0f / sqrtf(qt / (float)(n4 * 4) + eps);
+#pragma unroll
+  for (int j = 0; j < kGnMaxV; ++j) {
+    const int i = tid + j * 1024;
+    if (i < n4) {
+      const int c = (i % q4) * 4;
+      const f32x4 gg = *(const f32x4*)(g + grp * cpg + c), bb = *(const f32x4*)(b + grp * cpg + c);
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (v[j][r] - mean) * rstd * gg[r] + bb[r];
+      *(f32x4*)(yb + (size_t)(i / q4) * Cc + c) = o;
+    }
+  }
+}
+
 // Multi-scale deformable attention sampling (Deformable-DETR; F.grid_sample bilinear, zeros padding, align_corners=False).
 // value [B][S][H][dh]; loc [B][Q][H][L][P][2] in [0,1]; w [B][Q][H][L][P]; out [B][Q][H*dh]. One thread per (b,q,h,d).
 struct MsdShapes { int h[8], w[8], start[8]; };
@@ -473,7 +523,12 @@ int ovm_g_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, int6
 
 int ovm_g_groupnorm(const float* x, int32_t B, int32_t HW, int32_t Cc, int32_t groups, const float* gamma, const float* beta, float eps, float* y,
                     ovm_stream_t stream) {
-  hipLaunchKernelGGL(groupnorm_kernel, dim3(groups, B), dim3(256), 0, (hipStream_t)stream, x, HW, Cc, groups, gamma, beta, eps, y);
+  const int cpg = groups > 0 ? Cc / groups : 0;
+  const bool al16 = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0;
+  if (cpg > 0 && cpg % 4 == 0 && Cc % 4 == 0 && al16 && (long)HW * (cpg / 4) <= 1024L * kGnMaxV)
+    hipLaunchKernelGGL(groupnorm_reg_kernel, dim3(groups, B), dim3(1024), 0, (hipStream_t)stream, x, HW, Cc, groups, gamma, beta, eps, y);
+  else
+    hipLaunchKernelGGL(groupnorm_kernel, dim3(groups, B), dim3(256), 0, (hipStream_t)stream, x, HW, Cc, groups, gamma, beta, eps, y);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 

@@ -54,6 +54,13 @@ def test_generic_ops(device):
     gam, bet = torch.rand(64, generator=g).to(device), torch.randn(64, generator=g).to(device)
     ref = torch.nn.functional.group_norm(xn.cpu().permute(0, 2, 1), 8, gam.cpu(), bet.cpu(), 1e-5).permute(0, 2, 1)
     assert_close(o.groupnorm(xn, 8, gam, bet, 1e-5), ref, 5e-6, "groupnorm")
+    # the neck's shapes at a 532 x 532 image (register-resident kernel: 32 groups of 8 channels, 67 x 67 .. 9 x 9 pixels), a slice that does not
+    # fill the last round of loads, 6 channels per group (not a multiple of 4) and a level beyond the register budget (both: looping kernel)
+    for hw, cc, groups in ((67 * 67, 256, 32), (34 * 34, 256, 32), (81, 256, 32), (1030, 64, 4), (50, 48, 8), (120 * 110, 256, 32)):
+        xn = (torch.randn(1, hw, cc, generator=g) * 3.0 + 1.5).to(device)
+        gam, bet = torch.rand(cc, generator=g).to(device), torch.randn(cc, generator=g).to(device)
+        ref = torch.nn.functional.group_norm(xn.cpu().double().permute(0, 2, 1), groups, gam.cpu().double(), bet.cpu().double(), 1e-5).permute(0, 2, 1)
+        assert_close(o.groupnorm(xn, groups, gam, bet, 1e-5), ref.float(), 5e-6, f"groupnorm {hw}x{cc}/{groups}")
     sc = torch.randn(5000, generator=g).to(device)
     assert o.topk(sc, 900).cpu().tolist() == torch.topk(sc.cpu(), 900)[1].tolist()
     src = torch.randn(9, 6, generator=g).to(device)
