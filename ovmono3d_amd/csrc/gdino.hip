@@ -37,7 +37,7 @@ struct Lin {                       // packed nn.Linear: split-fp16 weight image 
   int N = 0, K = 0, Kpad = 0;
 };
 struct Ln { float* g = nullptr; float* b = nullptr; };
-struct SplitBuf { half_t* hi = nullptr; half_t* lo = nullptr; int ld = 0; };
+struct SplitBuf { half_t* hi = nullptr; half_t* lo = nullptr; int ld = 0; bool il = false; };   // il: one interleaved image [row][k/32][hi 32 | lo 32], lo = hi + 32, ld = 2 K
 
 struct SwinBlock { Ln ln1, ln2; Lin qkv, proj, fc1, fc2; float* relbias = nullptr; };
 struct SwinStage { std::vector<SwinBlock> blocks; int nh = 0, C = 0; bool has_red = false; Lin red; Ln dn; bool has_out = false; Ln on; };
@@ -60,9 +60,12 @@ static int g_gdino_branches = 1;
 void set_gdino_branches(int v) { g_gdino_branches = v ? 1 : 0; }
 static int g_gdino_dec_chain = 1;      // decoder layers as row-chain kernels (dec_chain.hip); read at capture time, like the branches
 void set_gdino_dec_chain(int v) { g_gdino_dec_chain = v ? 1 : 0; }
+static int g_gdino_gemm256 = 1;        // the wide K <= 256 contractions on the 256 x 256 GEMM (interleaved activations); read when a plan is built
+void set_gdino_gemm256(int v) { g_gdino_gemm256 = v ? 1 : 0; }
 }  // namespace ovm
 using ovm::g_gdino_branches;
 using ovm::g_gdino_dec_chain;
+using ovm::g_gdino_gemm256;
 
 constexpr size_t kSlabBytes = (size_t)256 << 20;
 
@@ -598,6 +601,15 @@ struct Run {
     }
     return b;
   }
+  // Interleaved split rows for the operands of the 256 x 256 GEMM (gemm256.hip): the encoder's and Swin stage 1's wide contractions
+  // over K <= 256 (752 / 564 / 556 tiles of 128 x 128, i.e. 2-3 rounds of a kernel whose per-round cost hardly depends on K) are one
+  // round of 256 x 256 tiles there. Falls back to planar rows when the kernel cannot take the shape (one-pass precision, K % 32).
+  SplitBuf split_for256(size_t rows, int K) {
+    if (g->npass != 3 || K % 32 || !g_gdino_gemm256) return split(rows, K);
+    SplitBuf b; b.il = true; b.ld = 2 * K;
+    b.hi = (half_t*)alloc(rows * b.ld * sizeof(half_t)); b.lo = b.hi ? b.hi + 32 : nullptr;
+    return b;
+  }
   size_t mark() const { return off; }
   void release(size_t m) { off = m; }
   void fail(int r, const char* what) { if (rc == OVM_OK) { rc = r; if (g->err.empty()) g->err = what; } }
@@ -611,11 +623,15 @@ struct Run {
   // big GEMM on the LDS-DMA kernels of gemm.hpp: A split fp16 [M][lda]
   GemmParams gp(const SplitBuf& A, int M, const Lin& W) {
     GemmParams p; memset(&p, 0, sizeof(p));
-    p.Ahi = A.hi; p.Alo = A.lo; p.lda = A.ld; p.Whi = W.hi; p.Wlo = W.lo; p.M = M; p.N = W.N; p.K = W.Kpad; p.bias = W.bias;
+    p.Ahi = A.hi; p.Alo = A.lo; p.lda = A.ld; p.a_il = A.il ? 1 : 0; p.Whi = W.hi; p.Wlo = W.lo; p.M = M; p.N = W.N; p.K = W.Kpad; p.bias = W.bias;
     p.ws_slot = 1; p.part_ws = ws; p.part_cap = ws_cap;
     return p;
   }
-  void gemm(const GemmParams& p, int epi) { if (go()) chk(launch_gemm(p, g->npass, epi, A_ROWMAJOR, s), "gemm"); }
+  void gemm(const GemmParams& p, int epi) {
+    if (!go()) return;
+    if (p.a_il && gemm256_supported(p, g->npass)) chk(launch_gemm256(p, epi, 1, s), "gemm256");
+    else chk(launch_gemm(p, g->npass, epi, A_ROWMAJOR, s), "gemm");
+  }
 
   // small / mid GEMM reading fp32 activations directly (gemm_small.hip): y = act((A + A2) W^T + b) (+ R)
   void lin(const float* A, const float* A2, int lda, int M, const Lin& W, int act, const float* R, int ldr, float* C, int ldc) {
@@ -627,7 +643,7 @@ struct Run {
   void ln(const float* x, int M, int D, const Ln& w, float eps, const float* res, float* y, SplitBuf* sp = nullptr) {
     RowOpParams p; memset(&p, 0, sizeof(p));
     p.x = x; p.ldx = D; p.res = res; p.ldr = D; p.gamma = w.g; p.beta = w.b; p.eps = eps; p.M = M; p.D = D; p.y = y; p.ldy = D;
-    if (sp) { p.hi = sp->hi; p.lo = sp->lo; p.ldh = sp->ld; }
+    if (sp) { p.hi = sp->hi; p.lo = sp->lo; p.ldh = sp->ld; p.il = sp->il ? 1 : 0; }
     rowop(p);
   }
   void attn(AttnF32Params p) { if (go()) chk(launch_attn_f32(p, s), "attn_f32"); }
@@ -751,7 +767,9 @@ int forward_impl(Run& r) {
       }
       // output projection; the epilogue un-partitions / un-shifts / crops through the same index map and adds the shortcut
       { GemmParams q = r.gp(ctx, M, blk.proj); q.X = x; q.ldx = C; q.row_map = wmaps.win; r.gemm(q, EPI_RESID); }
-      SplitBuf hn = r.split((size_t)ntok, C);
+      // stage 1 (17,689 tokens x 512 outputs over K = 128: 556 tiles of 128 x 128, or 140 of 256 x 256 in one round): interleaved rows
+      const bool wide = ((ntok + 127) / 128) * ((4 * C + 127) / 128) > 512 && (4 * C) % 256 == 0;
+      SplitBuf hn = wide ? r.split_for256((size_t)ntok, C) : r.split((size_t)ntok, C);
       r.ln(x, ntok, C, blk.ln2, eps, nullptr, nullptr, &hn);
       SplitBuf f1 = r.split((size_t)ntok, 4 * C);
       { GemmParams q = r.gp(hn, ntok, blk.fc1); q.Ohi = f1.hi; q.Olo = f1.lo; q.ldo = f1.ld; r.gemm(q, EPI_GELU); }
@@ -815,7 +833,7 @@ int forward_impl(Run& r) {
   const int HF = c.heads / 2, E = c.ffn_dim / 2, dhf = E / HF;
   {
     const size_t mk = r.mark();
-    float* v = r.f32((size_t)S * D); SplitBuf vsp = r.split((size_t)S, D);
+    float* v = r.f32((size_t)S * D); SplitBuf vsp = r.split_for256((size_t)S, D);      // A of vqv / de_fc1: S x 2048 outputs over K = 256
     float* t = r.f32((size_t)T * D);
     float* qvv = r.f32((size_t)S * 2 * E);              // [vision_proj | values_vision_proj]
     float* tkv = r.f32((size_t)T * 2 * E);              // [text_proj | values_text_proj]
@@ -932,10 +950,10 @@ int forward_impl(Run& r) {
     // projections that do not depend on the decoder state, all layers at once: text keys | values, deformable values of the memory
     float* tkv_all = r.f32((size_t)T * NL * 2 * D);
     r.lin(text, nullptr, D, T, g->dec_kv_text, 0, nullptr, 0, tkv_all, NL * 2 * D);
-    SplitBuf vsp = r.split((size_t)S, D);
+    SplitBuf vsp = r.split_for256((size_t)S, D);
     {
       RowOpParams p; memset(&p, 0, sizeof(p));
-      p.x = vis; p.ldx = D; p.M = S; p.D = D; p.hi = vsp.hi; p.lo = vsp.lo; p.ldh = vsp.ld;
+      p.x = vis; p.ldx = D; p.M = S; p.D = D; p.hi = vsp.hi; p.lo = vsp.lo; p.ldh = vsp.ld; p.il = vsp.il ? 1 : 0;
       r.rowop(p);
     }
     float* val_all = r.f32((size_t)S * NL * D);

@@ -19,6 +19,7 @@ struct RowOpParams {
   float* y; int ldy;                  // fp32 y (or null)
   float* y2; int ldy2;                // fp32 y2 (or null)
   half_t* hi; half_t* lo; int ldh;    // split fp16 of y, zero filled up to ldh (or null)
+  int il;                             // hi / lo form ONE interleaved image [row][k/32][hi 32 | lo 32] (lo = hi + 32, ldh = 2 D, D % 32 == 0): what gemm256 streams
   half_t* hi2; half_t* lo2; int ldh2; // split fp16 of y2
 };
 int launch_rowop(const RowOpParams& p, hipStream_t s);

@@ -44,11 +44,12 @@ __device__ __forceinline__ void rowop_store(const RowOpParams& p, int row, int e
     for (int i = 0; i < VEC; ++i) p.y[(size_t)row * p.ldy + e + i] = y[i];
   }
   if (p.hi) {
+    const int c0 = p.il ? il_col(e) : e;                  // VEC consecutive columns stay inside one 32-column group (e % VEC == 0, VEC <= 4)
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       half_t h, l; split_f16_nt(y[i], h, l);
-      p.hi[(size_t)row * p.ldh + e + i] = h;
-      if (p.lo) p.lo[(size_t)row * p.ldh + e + i] = l;
+      p.hi[(size_t)row * p.ldh + c0 + i] = h;
+      if (p.lo) p.lo[(size_t)row * p.ldh + c0 + i] = l;
     }
   }
   if (p.add) {
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void rowop_kernel(const RowOpParams p) {
     }
   }
   // zero fill of the K padding of the split images
-  if (p.hi && p.ldh > D)
+  if (p.hi && !p.il && p.ldh > D)
     for (int e = D + lane; e < p.ldh; e += 64) { p.hi[(size_t)row * p.ldh + e] = (half_t)0.f; if (p.lo) p.lo[(size_t)row * p.ldh + e] = (half_t)0.f; }
   if (p.hi2 && p.ldh2 > D)
     for (int e = D + lane; e < p.ldh2; e += 64) { p.hi2[(size_t)row * p.ldh2 + e] = (half_t)0.f; if (p.lo2) p.lo2[(size_t)row * p.ldh2 + e] = (half_t)0.f; }
@@ -577,6 +578,7 @@ __global__ void select_ref_kernel(const float* __restrict__ coord, int ldc, cons
 
 int launch_rowop(const RowOpParams& p, hipStream_t s) {
   if (p.M <= 0) return OVM_OK;
+  if (p.il && (!p.hi || p.lo != p.hi + 32 || p.D % 32 || p.ldh != 2 * p.D)) return OVM_ERR_INVALID;     // one interleaved image, no K padding
   const int seg = p.idx ? p.seg : p.D;
   auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
   const bool v4 = (p.D % 4 == 0) && (seg % 4 == 0) && (p.ldx % 4 == 0) && al16(p.x) && (!p.res || (p.ldr % 4 == 0 && al16(p.res)));
