@@ -280,14 +280,19 @@ __global__ __launch_bounds__(576) void attn_f32_kernel(const AttnF32Params p) {
 // ------------------------------------------------------------------------------------------------------------------------------
 // Fusion-layer bi-attention.
 // ------------------------------------------------------------------------------------------------------------------------------
-// image side: one wave per (image token, head); online softmax over the text tokens; also leaves the raw scores for the text side
+// image side: one wave per (image token, head); softmax over the text tokens; also leaves the raw scores for the text side.
+// The text tokens are taken 16 at a time: 16 independent dot products (their wave reductions overlap), one softmax step over the
+// block, 16 independent value rows. The first version walked the tokens one by one with the online-softmax update in between - a
+// serial chain of a wave reduction, two exponentials and a rescale per token: 56.8 us per launch at 6,015 tokens x 4 heads x 16 text
+// tokens, for 50 MB of traffic.
+template <int MAXE>                              // dh <= 256 * MAXE
 __global__ __launch_bounds__(256) void biattn_img_kernel(const BiAttnParams p) {
   const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (wid >= (long)p.S * p.H) return;
   const int s = (int)(wid / p.H), h = (int)(wid - (long)s * p.H);
   const int dh = p.dh;
-  constexpr int MAXE = 2;                       // dh <= 512
+  constexpr int TB = 16;
   f32x4 qv[MAXE], acc[MAXE];
 #pragma unroll
   for (int i = 0; i < MAXE; ++i) {
@@ -296,28 +301,48 @@ __global__ __launch_bounds__(256) void biattn_img_kernel(const BiAttnParams p) {
     acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   float m = -INFINITY, l = 0.f;
-  for (int t = 0; t < p.T; ++t) {
-    float d = 0.f;
+  for (int t0 = 0; t0 < p.T; t0 += TB) {
+    float d[TB];
 #pragma unroll
-    for (int i = 0; i < MAXE; ++i) {
-      const int e = (lane + 64 * i) * 4;
-      if (e < dh) {
-        const f32x4 kv = *(const f32x4*)(p.kt + (size_t)t * p.ldk + h * dh + e);
-        d += qv[i][0] * kv[0] + qv[i][1] * kv[1] + qv[i][2] * kv[2] + qv[i][3] * kv[3];
+    for (int j = 0; j < TB; ++j) {
+      const int t = (t0 + j < p.T) ? t0 + j : p.T - 1;          // clamped: the value is discarded below
+      float x = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXE; ++i) {
+        const int e = (lane + 64 * i) * 4;
+        if (e < dh) {
+          const f32x4 kv = *(const f32x4*)(p.kt + (size_t)t * p.ldk + h * dh + e);
+          x += qv[i][0] * kv[0] + qv[i][1] * kv[1] + qv[i][2] * kv[2] + qv[i][3] * kv[3];
+        }
       }
+      d[j] = x;
     }
-    d = wave_sum(d) * p.scale;
-    if (lane == 0) p.sc[((size_t)h * p.T + t) * p.S + s] = d;
-    const float mn = fmaxf(m, d);
-    const float alpha = expf(m - mn), pr = expf(d - mn);
-    l = l * alpha + pr;
+    float mine = 0.f, mb = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < MAXE; ++i) {
-      const int e = (lane + 64 * i) * 4;
-      if (e < dh) {
-        const f32x4 tv = *(const f32x4*)(p.vt + (size_t)t * p.ldvt + h * dh + e);
+    for (int j = 0; j < TB; ++j) {
+      d[j] = (t0 + j < p.T) ? wave_sum(d[j]) * p.scale : -INFINITY;
+      if (lane == j) mine = d[j];
+      mb = fmaxf(mb, d[j]);
+    }
+    if (lane < TB && t0 + lane < p.T) p.sc[((size_t)h * p.T + t0 + lane) * p.S + s] = mine;
+    const float mn = fmaxf(m, mb);
+    const float alpha = expf(m - mn);
+    l *= alpha;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][r] = acc[i][r] * alpha + pr * tv[r];
+    for (int i = 0; i < MAXE; ++i) { acc[i][0] *= alpha; acc[i][1] *= alpha; acc[i][2] *= alpha; acc[i][3] *= alpha; }
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      const float pr = expf(d[j] - mn);                         // -inf beyond T: 0
+      l += pr;
+      const int t = (t0 + j < p.T) ? t0 + j : p.T - 1;
+#pragma unroll
+      for (int i = 0; i < MAXE; ++i) {
+        const int e = (lane + 64 * i) * 4;
+        if (e < dh) {
+          const f32x4 tv = *(const f32x4*)(p.vt + (size_t)t * p.ldvt + h * dh + e);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][r] += pr * tv[r];
+        }
       }
     }
     m = mn;
@@ -664,7 +689,8 @@ int launch_relpos_tables(const float* q, int ldq, int M, int H, int DH, int gh, 
 
 int launch_biattn(const BiAttnParams& p, hipStream_t s) {
   if (p.dh % 4 || p.dh > 512 || p.chunk > 128 || p.chunk <= 0) return OVM_ERR_SHAPE;
-  hipLaunchKernelGGL(biattn_img_kernel, dim3((unsigned)(((long)p.S * p.H + 3) / 4)), dim3(256), 0, s, p);
+  if (p.dh <= 256) hipLaunchKernelGGL(biattn_img_kernel<1>, dim3((unsigned)(((long)p.S * p.H + 3) / 4)), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(biattn_img_kernel<2>, dim3((unsigned)(((long)p.S * p.H + 3) / 4)), dim3(256), 0, s, p);
   hipLaunchKernelGGL(biattn_stats_kernel, dim3(p.H * p.T), dim3(256), 0, s, p);
   hipLaunchKernelGGL(biattn_txt_partial_kernel, dim3(p.nchunk, p.H), dim3(256), 0, s, p);
   hipLaunchKernelGGL(biattn_txt_combine_kernel, g1((long)p.T * p.H * p.dh), dim3(256), 0, s, p);

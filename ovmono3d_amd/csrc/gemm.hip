@@ -60,8 +60,9 @@ static int launch_ws(const GemmParams& p, hipStream_t s) {
   // k-steps: split K over workgroups (deterministic: partial tiles + one reduce/epilogue pass)
   // (also the GroundingDINO engine's Swin proj / fc2 GEMMs: 40-90 tiles with 16-64 k-tiles, residual epilogue: the reduce
   // pass applies any epilogue, EPI_QKV's V^T scatter excepted)
-  if (g_splitk && (EPI != EPI_QKV && EPI != EPI_PATCH && EPI != EPI_CONVT) && tiles_full <= 96 && nk >= 32 && p.N % 4 == 0) {
-    int ks = 256 / tiles_full; if (ks > 16) ks = 16; if (ks > nk / 8) ks = nk / 8;
+  const int min_nk = g_splitk >= 2 ? 16 : 32, min_steps = g_splitk >= 2 ? 4 : 8;     // experiment (gemm_splitk 2): slices of >= 4 k-steps from 16 k-steps on
+  if (g_splitk && (EPI != EPI_QKV && EPI != EPI_PATCH && EPI != EPI_CONVT) && tiles_full <= 96 && nk >= min_nk && p.N % 4 == 0) {
+    int ks = 256 / tiles_full; if (ks > 16) ks = 16; if (ks > nk / min_steps) ks = nk / min_steps;
     if (ks > 1) {
       const int chunk = (nk + ks - 1) / ks;
       ks = (nk + chunk - 1) / chunk;

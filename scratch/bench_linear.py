@@ -1,8 +1,9 @@
 """us per call of the generic projection on the shapes the GroundingDINO branch issues (calls queued back to back)."""
 import sys, os, torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 from ovmono3d_amd import lib as _lib
-from ovmono3d_amd.gdino.ops import Ops
+from pyref_gdino.ops import Ops
 dev = torch.device("cuda:0")
 o = Ops(dev, int(os.environ.get("PREC", "3")))
 L = _lib.load()
@@ -10,6 +11,8 @@ SH = [(900, 256, 256, 62), (1156, 512, 2048, 18), (1156, 2048, 512, 18), (1296, 
       (6015, 1024, 256, 12), (6015, 256, 1024, 6), (6015, 256, 2048, 6), (6015, 2048, 256, 6), (16, 256, 256, 36), (16, 1024, 256, 18),
       (16, 768, 3072, 12), (16, 3072, 768, 12), (16, 2304, 768, 12), (16, 768, 768, 12), (5184, 768, 256, 2), (5184, 1024, 256, 2),
       (4489, 256, 1024, 2), (20736, 384, 128, 2), (20736, 512, 128, 2), (17689, 128, 512, 2), (900, 256, 2048, 6), (900, 2048, 256, 6)]
+if os.environ.get("SHAPES"):
+    SH = [tuple(int(v) for v in t.split("x")) + (1,) for t in os.environ["SHAPES"].split(",")]
 cfgs = [c for c in os.environ.get("CFGS", "").split(";") if c] or [""]
 rows = {}
 for cfg in cfgs:
