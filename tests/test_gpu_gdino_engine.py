@@ -320,3 +320,30 @@ def test_decoder_row_chain_matches_launch_per_op_decoder(device, size):
     assert torch.isfinite(outs[1][0]).all() and torch.isfinite(outs[1][1]).all()
     assert_close(outs[1][1], outs[0][1], 2e-5, "pred_boxes (row chain vs launch per op)")
     assert_close(outs[1][0], outs[0][0], 2e-5, "pred_logits (row chain vs launch per op)")
+
+
+def test_wide_contractions_on_256_tiles_match_128_tiles(device):
+    """Round 3: the detector's wide contractions over K <= 256 (encoder vision q|v and FFN up-projection, decoder value projection, Swin
+    stage 1 FFN up-projection) run on the 256 x 256 GEMM, their LayerNorm writing interleaved split rows (Run::split_for256). Against the
+    128-tile route (ovm_tune_set gdino_gemm256 = 0) on the full-size detector: same three-pass products, fp32 accumulation; the k-order
+    inside a tile and the old route's split-K differ - logits and boxes to 2e-5."""
+    from ovmono3d_amd import lib
+    from ovmono3d_amd.util.synth_gdino_weights import synth_gdino_state_dict
+    L = lib.load()
+    g = torch.Generator().manual_seed(13)
+    sd, hw = synth_gdino_state_dict(3), (532, 532)
+    ids = [101, 2000 + 17, 1012, 2000 + 29, 2000 + 31, 1012, 2000 + 5, 1012, 102]
+    img = torch.randint(0, 256, (3,) + hw, dtype=torch.uint8, generator=g).to(device)
+    outs = []
+    try:
+        for val in (0, 1):
+            assert L.ovm_tune_set(b"gdino_gemm256", val) == 0
+            eng = _engine(device, sd, {}, use_graphs=False)
+            logits, boxes = eng.forward(img, ids)
+            outs.append((logits[:, :len(ids)].clone(), boxes.clone()))
+            del eng
+    finally:
+        L.ovm_tune_set(b"gdino_gemm256", 1)
+    assert torch.isfinite(outs[1][0]).all() and torch.isfinite(outs[1][1]).all()
+    assert_close(outs[1][1], outs[0][1], 2e-5, "pred_boxes (256 x 256 tiles vs 128 x 128)")
+    assert_close(outs[1][0], outs[0][0], 2e-5, "pred_logits (256 x 256 tiles vs 128 x 128)")
