@@ -188,6 +188,8 @@ __device__ __forceinline__ void store_rows(const float* src, int lds_, int row0,
 
 }  // namespace
 
+__device__ __forceinline__ void chain_tail(const DecChainParams& p, const Lds& l, int row0);
+
 // ------------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void dec_chain_a_kernel(const DecChainParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -333,12 +335,27 @@ __global__ __launch_bounds__(NT) void dec_chain_b_kernel(const DecChainParams p)
   {
     const int ffn = p.ffn, chunk = ffn < KMAX ? ffn : KMAX, ldh = KMAX + 4;
     __syncthreads();
+    if (p.ffn_split > 1) {                                   // this workgroup's chunk only; chain C adds the partials up
+      const int c0 = (int)blockIdx.y * chunk;
+      if (blockIdx.y == 0) store_rows(l.x0, l.ldf, row0, p.Q, D, p.ffn_x, D);
+      chain_lin(l, l.x0, nullptr, l.ldf, D, p.fc1, 0, c0, chunk, chunk, p.fc1.bias + c0, 1, nullptr, 0, false, l.u, ldh);
+      chain_lin(l, l.u, nullptr, ldh, chunk, p.fc2, c0, 0, D, D, nullptr, 0, nullptr, 0, false, l.t1, l.ldf);
+      __syncthreads();
+      store_rows(l.t1, l.ldf, row0, p.Q, D, p.ffn_part + (size_t)blockIdx.y * p.Q * D, D);
+      return;
+    }
     for (int i = tid; i < R * D; i += NT) { const int row = i / D, c = i - row * D; l.t1[row * l.ldf + c] = l.x0[row * l.ldf + c] + p.fc2.bias[c]; }
     for (int c0 = 0; c0 < ffn; c0 += chunk) {
       chain_lin(l, l.x0, nullptr, l.ldf, D, p.fc1, 0, c0, chunk, chunk, p.fc1.bias + c0, 1, nullptr, 0, false, l.u, ldh);
       chain_lin(l, l.u, nullptr, ldh, chunk, p.fc2, c0, 0, D, D, nullptr, 0, nullptr, 0, true, l.t1, l.ldf);
     }
   }
+  chain_tail(p, l, row0);
+}
+
+// LN4 of the FFN output in t1 -> decoder state; iterative box refinement
+__device__ __forceinline__ void chain_tail(const DecChainParams& p, const Lds& l, int row0) {
+  const int D = p.D, tid = threadIdx.x;
   chain_ln(l.t1, l.ldf, D, p.ln4, p.eps, l.x0, l.ldf);
   __syncthreads();
   store_rows(l.x0, l.ldf, row0, p.Q, D, p.hs, D);
@@ -360,6 +377,21 @@ __global__ __launch_bounds__(NT) void dec_chain_b_kernel(const DecChainParams p)
   }
 }
 
+// chain C (ffn_split > 1): t1 = (x + b2) + partial 0 + partial 1 + ... (the single workgroup's accumulation order), then the tail
+__global__ __launch_bounds__(NT) void dec_chain_c_kernel(const DecChainParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const Lds l = carve(smem, p.D, p.dbg_skip);
+  const int D = p.D, row0 = blockIdx.x * R, tid = threadIdx.x;
+  for (int i = tid; i < R * D; i += NT) {
+    const int row = i / D, c = i - row * D;
+    int gr = row0 + row; if (gr > p.Q - 1) gr = p.Q - 1;
+    float y = p.ffn_x[(size_t)gr * D + c] + p.fc2.bias[c];
+    for (int sl = 0; sl < p.ffn_split; ++sl) y += p.ffn_part[((size_t)sl * p.Q + gr) * D + c];
+    l.t1[row * l.ldf + c] = y;
+  }
+  chain_tail(p, l, row0);
+}
+
 size_t dec_chain_lds_bytes(int D) {
   return (size_t)4 * R * (D + 4) * sizeof(float) + (size_t)2 * R * XLD * sizeof(half_t) + (size_t)R * (KMAX + 4) * sizeof(float);
 }
@@ -377,12 +409,18 @@ int launch_dec_chain(const DecChainParams& p, int part, hipStream_t s) {
   static bool set = false;
   if (!set) {
     if (hipFuncSetAttribute((const void*)dec_chain_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)dec_chain_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return OVM_ERR_HIP;
+        hipFuncSetAttribute((const void*)dec_chain_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)dec_chain_c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return OVM_ERR_HIP;
     set = true;
   }
   const dim3 grid((p.Q + R - 1) / R), block(NT);
+  if (p.ffn_split > 1) {
+    const int chunk = p.ffn < KMAX ? p.ffn : KMAX;
+    if (p.ffn_split * chunk != p.ffn || !p.ffn_x || !p.ffn_part) return OVM_ERR_INVALID;
+  } else if (part == 2) return OVM_ERR_INVALID;
   if (part == 0) hipLaunchKernelGGL(dec_chain_a_kernel, grid, block, smem, s, p);
-  else hipLaunchKernelGGL(dec_chain_b_kernel, grid, block, smem, s, p);
+  else if (part == 1) hipLaunchKernelGGL(dec_chain_b_kernel, dim3(grid.x, p.ffn_split > 1 ? p.ffn_split : 1), block, smem, s, p);
+  else hipLaunchKernelGGL(dec_chain_c_kernel, grid, block, smem, s, p);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 

@@ -24,12 +24,19 @@ struct DecChainParams {
   int L, P; int lh[8], lw[8], lstart[8];
   ChainLin ref0, ref1, sa_qk, sa_v, sa_out, ca_q, ca_out, offw, msda_out, fc1, fc2, bb0, bb1, bb2;
   ChainLn ln1, ln2, ln3, ln4;
+  // FFN split (ffn_split > 1): chain B runs as a (row blocks) x (hidden chunks) grid - every workgroup of a row block repeats the
+  // cheap front of the layer, computes ONE 512-column chunk of the hidden layer and writes its partial second-layer product; chain C
+  // (one workgroup per row block) adds the partials in chunk order to (x + bias) - the order the single workgroup used - and finishes
+  // the layer (LN4, state, box refinement). 57 workgroups streaming 4 MB of FFN weights each become 228 streaming 1 MB.
+  int ffn_split;
+  float* ffn_x;                     // [Q][D]  FFN input (= residual), written by the chunk-0 workgroups
+  float* ffn_part;                  // [ffn_split][Q][D] partial products
   unsigned long long* dbg_stamps;   // -DOVM_DIAG: s_memtime stamps of workgroup 0 (chain A: [0..31], chain B: [32..95])
   int dbg_skip;                     // -DOVM_DIAG builds only (env OVM_DEC_CHAIN_SKIP): timing ablations, results are wrong when non-zero
 };
 
 bool dec_chain_supported(int D, int heads, int ffn, int L, int P, int T, int npass);
-// part 0: chain A (before the query self-attention), part 1: chain B (after it)
+// part 0: chain A (before the query self-attention), part 1: chain B (after it), part 2: chain C (only with ffn_split > 1)
 int launch_dec_chain(const DecChainParams& p, int part, hipStream_t s);
 
 }  // namespace ovm

@@ -60,12 +60,16 @@ static int g_gdino_branches = 1;
 void set_gdino_branches(int v) { g_gdino_branches = v ? 1 : 0; }
 static int g_gdino_dec_chain = 1;      // decoder layers as row-chain kernels (dec_chain.hip); read at capture time, like the branches
 void set_gdino_dec_chain(int v) { g_gdino_dec_chain = v ? 1 : 0; }
+static int g_gdino_ffn_split = 0;      // decoder chain B over (row blocks) x (FFN chunks) + chain C; read when a plan is built. Bit-identical; 8.61 -> 8.34 ms
+                                       // for the detector ALONE, but 51.14 -> 50.97 images/s beside the ViT (four times the workgroups on the chip): off
+void set_gdino_ffn_split(int v) { g_gdino_ffn_split = v ? 1 : 0; }
 static int g_gdino_gemm256 = 1;        // the wide K <= 256 contractions on the 256 x 256 GEMM (interleaved activations); read when a plan is built
 void set_gdino_gemm256(int v) { g_gdino_gemm256 = v ? 1 : 0; }
 }  // namespace ovm
 using ovm::g_gdino_branches;
 using ovm::g_gdino_dec_chain;
 using ovm::g_gdino_gemm256;
+using ovm::g_gdino_ffn_split;
 
 constexpr size_t kSlabBytes = (size_t)256 << 20;
 
@@ -975,10 +979,15 @@ int forward_impl(Run& r) {
     const bool chain = g_gdino_dec_chain && dec_chain_supported(D, c.heads, c.ffn_dim, c.n_levels, c.n_points, T, g->npass);
     auto cl = [](const Lin& w) { return ChainLin{w.frag, w.bias, w.N, w.K, w.Kpad}; };
     auto cn = [](const Ln& w) { return ChainLn{w.g, w.b}; };
+    const int ffn_chunks = c.ffn_dim > 512 ? c.ffn_dim / 512 : 1;
+    const bool ffn_split = chain && g_gdino_ffn_split && ffn_chunks > 1;
+    float* ffn_x = ffn_split ? r.f32((size_t)Q * D) : nullptr;
+    float* ffn_part = ffn_split ? r.f32((size_t)ffn_chunks * Q * D) : nullptr;
     for (int i = 0; i < NL && chain; ++i) {
       DecLayer& ly = g->dec[i];
       float* rf = refs[cur];
       DecChainParams dp; memset(&dp, 0, sizeof(dp));
+      if (ffn_split) { dp.ffn_split = ffn_chunks; dp.ffn_x = ffn_x; dp.ffn_part = ffn_part; }
       dp.Q = Q; dp.D = D; dp.T = T; dp.heads = c.heads; dp.ffn = c.ffn_dim; dp.eps = eps;
       dp.sine_dim_t = g->sine_dim_t;
       dp.hs = hs; dp.ref = rf; dp.ref_next = (i + 1 < NL) ? refs[cur ^ 1] : nullptr;
@@ -1014,6 +1023,7 @@ int forward_impl(Run& r) {
 #endif
       mha_core(r, qk, 2 * D, qk + D, 2 * D, vq, D, Q, Q, ly.sa.heads, D, nullptr, 0, ctx, D);
       if (r.go()) r.chk(launch_dec_chain(dp, 1, s), "dec_chain_b");
+      if (ffn_split && r.go()) r.chk(launch_dec_chain(dp, 2, s), "dec_chain_c");
       if (i == NL - 1) { if (r.go()) GCHECK(g, hipMemcpyAsync(last_ref, rf, sizeof(float) * (size_t)Q * 4, hipMemcpyDeviceToDevice, s)); }
       r.tap(("dec_hs" + std::to_string(i)).c_str(), hs, (int64_t)Q * D);
       if (i + 1 < NL) cur ^= 1;

@@ -7,7 +7,7 @@ from common import build_cfg
 from ovmono3d_amd.gdino.detector import HashTokenizer
 from ovmono3d_amd.gdino.engine import GdinoEngine
 from ovmono3d_amd.modeling import build_model
-from ovmono3d_amd.util.synth_gdino import synth_gdino_model
+from synth_gdino import synth_gdino_model
 from ovmono3d_amd.util.synth_weights import synth_state_dict
 dev = torch.device("cuda:0")
 from ovmono3d_amd import lib as _lib

@@ -347,3 +347,39 @@ def test_wide_contractions_on_256_tiles_match_128_tiles(device):
     assert torch.isfinite(outs[1][0]).all() and torch.isfinite(outs[1][1]).all()
     assert_close(outs[1][1], outs[0][1], 2e-5, "pred_boxes (256 x 256 tiles vs 128 x 128)")
     assert_close(outs[1][0], outs[0][0], 2e-5, "pred_logits (256 x 256 tiles vs 128 x 128)")
+
+
+@pytest.mark.parametrize("size", ["small", "full"])
+def test_decoder_ffn_chunks_on_separate_workgroups_is_bit_identical(device, size):
+    """Round 3: chain B of a decoder layer runs as (row blocks) x (FFN chunks of 512 hidden columns) - every workgroup of a row block
+    repeats the front of the layer and computes one chunk's partial second-layer product - and chain C adds the partials to
+    (x + bias) in chunk order, the accumulation order of the one-workgroup form, then finishes the layer. Nothing else changes, so
+    logits and boxes must agree in every bit with ovm_tune_set gdino_ffn_split = 0."""
+    from ovmono3d_amd import lib
+    L = lib.load()
+    g = torch.Generator().manual_seed(17)
+    if size == "small":
+        hf, _ = _small_hf_gdino()
+        sd, cfgk, hw = hf.state_dict(), SMALL, (120, 168)
+        ids = [101, 500, 1012, 600, 601, 1012, 102]
+    else:
+        from ovmono3d_amd.util.synth_gdino_weights import synth_gdino_state_dict
+        sd, cfgk, hw = synth_gdino_state_dict(3), {}, (532, 620)
+        ids = [101, 2000 + 17, 1012, 2000 + 29, 2000 + 31, 1012, 2000 + 5, 1012, 102]
+    img = torch.randint(0, 256, (3,) + hw, dtype=torch.uint8, generator=g).to(device)
+    outs, launches = [], []
+    try:
+        for split in (0, 1):
+            assert L.ovm_tune_set(b"gdino_ffn_split", split) == 0
+            eng = _engine(device, sd, cfgk, use_graphs=False)
+            logits, boxes = eng.forward(img, ids)
+            outs.append((logits.clone(), boxes.clone()))
+            launches.append(eng.launches())
+            del eng
+    finally:
+        L.ovm_tune_set(b"gdino_ffn_split", 0)
+    from ovmono3d_amd.gdino.config import GDinoConfig
+    cfg = GDinoConfig(**cfgk)
+    if cfg.ffn_dim > 512:
+        assert launches[1] == launches[0] + cfg.dec_layers, launches       # one finishing kernel per layer (else this test compares a kernel with itself)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
