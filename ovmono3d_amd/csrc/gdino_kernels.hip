@@ -408,10 +408,19 @@ __global__ __launch_bounds__(256) void biattn_txt_partial_kernel(const BiAttnPar
 #pragma unroll
       for (int t = 0; t < TB; ++t) acc[t] = 0.f;
       const float* vcol = p.vv + (size_t)s0 * p.ldvv + h * p.dh + d;
-      for (int si = 0; si < ns; ++si) {
-        const float x = vcol[(size_t)si * p.ldvv];
+      // eight value rows in flight per thread (the one-row-at-a-time loop exposed a memory latency per image token: 41 us per launch
+      // for 25 MB); rows past the chunk's end re-read its last row against pr = 0, the sums keep their order
+      for (int si = 0; si < ns; si += 8) {
+        float x[8];
 #pragma unroll
-        for (int t = 0; t < TB; ++t) acc[t] = fmaf(pr[t][si], x, acc[t]);
+        for (int j = 0; j < 8; ++j) { const int r = (si + j < ns) ? si + j : ns - 1; x[j] = vcol[(size_t)r * p.ldvv]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (si + j < CH) {
+#pragma unroll
+            for (int t = 0; t < TB; ++t) acc[t] = fmaf(pr[t][si + j], x[j], acc[t]);
+          }
+        }
       }
       for (int t = 0; t < nt; ++t) p.part[((size_t)c * p.T + t0 + t) * E + h * p.dh + d] = acc[t];
     }
