@@ -352,6 +352,7 @@ int ovm_g_topk(const float* scores, int32_t n, int32_t k, int32_t* out_idx, ovm_
  *   kernel; default 0: measured slower), attn_pp 0|1 (two-wave-group attention kernel), msdeform_vec 0|1 (vectorised deformable sampling;
  *   default 1), gdino_dec_chain 0|1 (GroundingDINO decoder layers as row-chain kernels; default 1; read when a plan is built),
  *   gdino_ffn_split 0|1 (decoder row chains: the FFN's 512-column chunks on separate workgroups + a finishing kernel; bit-identical, faster for the detector alone, not beside the ViT; default 0; read when a plan is built),
+ *   gdino_swin_fused 0|1 (Swin blocks: qkv projection inside the window-attention kernel; default 1; read when a plan is built),
  *   gdino_gemm256 0|1 (the detector's wide K <= 256 contractions on the 256 x 256 kernel; default 1; read when a plan is built),
  *   gdino_branches 0|1. Values that select timing-only ablations with wrong results exist in -DOVM_DIAG builds only. */
 int ovm_tune_set(const char* key, int32_t value);

@@ -63,6 +63,8 @@ void set_gdino_dec_chain(int v) { g_gdino_dec_chain = v ? 1 : 0; }
 static int g_gdino_ffn_split = 0;      // decoder chain B over (row blocks) x (FFN chunks) + chain C; read when a plan is built. Bit-identical; 8.61 -> 8.34 ms
                                        // for the detector ALONE, but 51.14 -> 50.97 images/s beside the ViT (four times the workgroups on the chip): off
 void set_gdino_ffn_split(int v) { g_gdino_ffn_split = v ? 1 : 0; }
+static int g_gdino_swin_fused = 1;     // Swin blocks: qkv projection inside the window-attention kernel; read when a plan is built
+void set_gdino_swin_fused(int v) { g_gdino_swin_fused = v ? 1 : 0; }
 static int g_gdino_gemm256 = 1;        // the wide K <= 256 contractions on the 256 x 256 GEMM (interleaved activations); read when a plan is built
 void set_gdino_gemm256(int v) { g_gdino_gemm256 = v ? 1 : 0; }
 }  // namespace ovm
@@ -70,6 +72,7 @@ using ovm::g_gdino_branches;
 using ovm::g_gdino_dec_chain;
 using ovm::g_gdino_gemm256;
 using ovm::g_gdino_ffn_split;
+using ovm::g_gdino_swin_fused;
 
 constexpr size_t kSlabBytes = (size_t)256 << 20;
 
@@ -755,10 +758,19 @@ int forward_impl(Run& r) {
         p.M = M; p.D = C; p.hi = xw.hi; p.lo = xw.lo; p.ldh = xw.ld;
         r.rowop(p);
       }
+      SplitBuf ctx = r.split((size_t)M, C);
+      const bool fused = g_gdino_swin_fused && blk.qkv.frag && dh == 32 && swin_qkv_attn_supported(C, nh, ws, g->npass) && xw.ld % 8 == 0;
+      if (fused) {
+        // qkv projection inside the window kernel (one workgroup per (window, head)): no [M][3 C] fp32 round trip, one launch less
+        SwinQkvAttnParams a; memset(&a, 0, sizeof(a));
+        a.xhi = xw.hi; a.xlo = xw.lo; a.ldx = xw.ld; a.wfrag = blk.qkv.frag; a.KS = blk.qkv.Kpad / 32; a.bias = blk.qkv.bias;
+        a.C = C; a.nh = nh; a.nW = nW; a.relbias = blk.relbias; a.mask = wmaps.mask; a.ohi = ctx.hi; a.olo = ctx.lo; a.ldo = ctx.ld;
+        a.scale = 1.0f / sqrtf((float)dh);
+        if (r.go()) r.chk(launch_swin_qkv_attn(a, s), "swin_qkv_attn");
+      } else {
       float* qkv = r.f32((size_t)M * 3 * C);
       { GemmParams q = r.gp(xw, M, blk.qkv); q.C = qkv; q.ldc = 3 * C; r.gemm(q, EPI_STORE); }
       // window attention: QK^T + relative-position bias + shift mask + softmax + PV, one workgroup per (window, head)
-      SplitBuf ctx = r.split((size_t)M, C);
       {
         AttnF32Params a; memset(&a, 0, sizeof(a));
         a.q = qkv; a.k = qkv + C; a.v = qkv + 2 * C; a.ldq = a.ldk = a.ldv = 3 * C;
@@ -768,6 +780,7 @@ int forward_impl(Run& r) {
         a.bias_h = blk.relbias; a.sbh = (long)ws2 * ws2; a.ldbh = ws2;
         a.bias_b = wmaps.mask; a.sbb = (long)ws2 * ws2; a.ldbb = ws2;
         r.attn(a);
+      }
       }
       // output projection; the epilogue un-partitions / un-shifts / crops through the same index map and adds the shortcut
       { GemmParams q = r.gp(ctx, M, blk.proj); q.X = x; q.ldx = C; q.row_map = wmaps.win; r.gemm(q, EPI_RESID); }
@@ -1161,6 +1174,7 @@ int ovm_gdino_create(const OvmGdinoConfig* cfg, const OvmTensor* weights, int32_
         RCHECK(g, up_ln(g, wm, q + "layernorm_before", &blk.ln1));
         RCHECK(g, up_ln(g, wm, q + "layernorm_after", &blk.ln2));
         RCHECK(g, pack_cat(g, wm, {q + "attention.q_proj", q + "attention.k_proj", q + "attention.v_proj"}, &blk.qkv));
+        if (swin_qkv_attn_supported(C, st.nh, ws, g->npass)) RCHECK(g, make_frag(g, &blk.qkv));      // the window kernel projects q | k | v itself
         RCHECK(g, pack_lin(g, wm, q + "attention.o_proj", &blk.proj));
         RCHECK(g, pack_lin(g, wm, q + "mlp.fc1", &blk.fc1));
         RCHECK(g, pack_lin(g, wm, q + "mlp.fc2", &blk.fc2));

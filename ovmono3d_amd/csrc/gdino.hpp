@@ -42,6 +42,22 @@ struct AttnF32Params {
 };
 int launch_attn_f32(const AttnF32Params& p, hipStream_t s);
 
+// ---- Swin window attention with its qkv projection inside (round 3): one workgroup per (window, head), windows of 144 tokens, head
+// dimension 32. [q | k | v] of the head = x_window W_head^T + b over split-fp16 rows straight from HBM (three-pass MFMA, weights in
+// MFMA-fragment order) lands in LDS in the layouts attn_f32_kernel stages; then that kernel's score / softmax / value loop.
+struct SwinQkvAttnParams {
+  const half_t* xhi; const half_t* xlo; int ldx;   // window-partitioned LayerNorm rows [nW * 144][ldx] (planar split fp16)
+  const half_t* wfrag; int KS;                     // qkv weight image in fragment order (make_frag), KS = Kpad / 32 k-steps
+  const float* bias;                               // [3 C]
+  int C, nh, nW;
+  const float* relbias;                            // [nh][144][144]
+  const float* mask;                               // [nW][144][144] or null
+  half_t* ohi; half_t* olo; int ldo;               // context rows [nW * 144][ldo] (planar split fp16), head h at columns 32 h ..
+  float scale;
+};
+bool swin_qkv_attn_supported(int C, int nh, int ws, int npass);
+int launch_swin_qkv_attn(const SwinQkvAttnParams& p, hipStream_t s);
+
 // rel_h[(m * H + h)][kh] = q[m][h*DH : (h+1)*DH] . Rh[qh - kh + gh - 1], rel_w likewise over kw with Rw and qw, for the rows m of
 // fp32 q (row stride ldq); a row's position on its gh x gw attention grid is (t / gw, t % gw) with t = m % (gh * gw)
 int launch_relpos_tables(const float* q, int ldq, int M, int H, int DH, int gh, int gw, const float* Rh, const float* Rw, float* rel_h,

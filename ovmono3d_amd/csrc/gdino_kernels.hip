@@ -278,6 +278,164 @@ __global__ __launch_bounds__(576) void attn_f32_kernel(const AttnF32Params p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// Swin window attention with the qkv projection inside. Phase 1: the 9 waves form a 3 x 3 grid over (48 window rows) x (q | k | v of
+// the head): per k-step a lane loads 6 activation fragments (3 row tiles x hi / lo, 16 B each, straight from the split rows in HBM)
+// and 4 weight fragments (2 column tiles x hi / lo, 1 KiB contiguous per instruction in the fragment-ordered image), the next step's
+// loads are issued before this step's 18 MFMAs. Same products in the same order as the 128-tile GEMM (lo . hi, hi . lo, hi . hi per
+// k-step of 32). The accumulators go to LDS as Q rows [144][36], K rows [144][36] and V transposed [32][148] - what attn_f32_kernel
+// stages from HBM. Phase 2: that kernel's loop for one chunk of 144 keys (wave = 16 queries).
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(576) void swin_qkv_attn_kernel(const SwinQkvAttnParams p) {
+  constexpr int DH = 32, WS2 = 144, LDK = DH + 4, LDT = WS2 + 4, NS = DH / 4, ND = DH / 16, NKT = WS2 / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* Qs = (float*)smem_raw;                // [144][LDK]
+  float* Ks = Qs + WS2 * LDK;                  // [144][LDK]
+  float* Vt = Ks + WS2 * LDK;                  // [DH][LDT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int w = (int)blockIdx.x / p.nh, h = (int)blockIdx.x - w * p.nh;
+  // ---------------- phase 1: [q | k | v] = x W^T + b ----------------
+  {
+    const int mg = wave / 3, ng = wave - mg * 3;              // rows 48 mg .. 48 mg + 47; part ng: 0 = q, 1 = k, 2 = v
+    const int tile0 = (ng * p.C + h * DH) >> 4;               // first of the two 16-row weight tiles of this part and head
+    const half_t* xh = p.xhi + (size_t)(w * WS2 + mg * 48 + fr) * p.ldx + fq * 8;
+    const half_t* xl = p.xlo + (size_t)(w * WS2 + mg * 48 + fr) * p.ldx + fq * 8;
+    const half_t* wp = p.wfrag + (size_t)tile0 * p.KS * 1024 + lane * 8;       // tile stride = KS * (hi 512 + lo 512) halves
+    const size_t wt = (size_t)p.KS * 1024;
+    f32x4 acc[2][3];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // The weights come from HBM (cold: the detector streams ~0.9 GB of them per forward beside the ViT's 1.2 GB), the activation rows
+    // from L2: weight fragments are kept THREE k-steps ahead (4 register slots), activation fragments one step ahead (2 slots).
+    half8 xa[2][6], wa[4][4];
+    auto loadx = [&](int ks, half8* xd) {
+      const int k = (ks < p.KS) ? ks : p.KS - 1;              // past the end: re-load the last step (never used)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        xd[2 * m] = *(const half8*)(xh + (size_t)m * 16 * p.ldx + k * 32);
+        xd[2 * m + 1] = *(const half8*)(xl + (size_t)m * 16 * p.ldx + k * 32);
+      }
+    };
+    auto loadw = [&](int ks, half8* wd) {
+      const int k = (ks < p.KS) ? ks : p.KS - 1;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        wd[2 * n] = *(const half8*)(wp + n * wt + (size_t)k * 1024);
+        wd[2 * n + 1] = *(const half8*)(wp + n * wt + (size_t)k * 1024 + 512);
+      }
+    };
+    auto mfmak = [&](const half8* xd, const half8* wd) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wd[2 * n + 1], xd[2 * m], acc[n][m], 0, 0, 0);
+          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wd[2 * n], xd[2 * m + 1], acc[n][m], 0, 0, 0);
+          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wd[2 * n], xd[2 * m], acc[n][m], 0, 0, 0);
+        }
+    };
+    loadw(0, wa[0]); loadw(1, wa[1]); loadw(2, wa[2]); loadx(0, xa[0]);
+    for (int ks = 0; ks < p.KS; ks += 4) {                    // KS % 4 == 0 (C % 128 == 0, launcher)
+      // sched_barrier(0): left alone the scheduler sinks the loads next to their uses (80 VGPRs, nothing in flight under the MFMAs)
+#define OVM_SWIN_STEP(KW, WS, KX, XS, XC, WC)                                                   \
+      loadw(KW, wa[WS]); loadx(KX, xa[XS]); __builtin_amdgcn_sched_barrier(0);                  \
+      mfmak(xa[XC], wa[WC]); __builtin_amdgcn_sched_barrier(0);
+      OVM_SWIN_STEP(ks + 3, 3, ks + 1, 1, 0, 0)
+      OVM_SWIN_STEP(ks + 4, 0, ks + 2, 0, 1, 1)
+      OVM_SWIN_STEP(ks + 5, 1, ks + 3, 1, 0, 2)
+      OVM_SWIN_STEP(ks + 6, 2, ks + 4, 0, 1, 3)
+#undef OVM_SWIN_STEP
+    }
+    // lane (fr, fq) holds row m = fr of a row tile, columns 4 fq .. 4 fq + 3 of a column tile (dec_chain.hip's convention)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int d0 = n * 16 + fq * 4;
+      const f32x4 b = *(const f32x4*)(p.bias + ng * p.C + h * DH + d0);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const int row = mg * 48 + m * 16 + fr;
+        const f32x4 y = (f32x4){acc[n][m][0] + b[0], acc[n][m][1] + b[1], acc[n][m][2] + b[2], acc[n][m][3] + b[3]};
+        if (ng == 0) *(f32x4*)(Qs + row * LDK + d0) = y;
+        else if (ng == 1) *(f32x4*)(Ks + row * LDK + d0) = y;
+        else { float* vd = Vt + d0 * LDT + row; vd[0] = y[0]; vd[LDT] = y[1]; vd[2 * LDT] = y[2]; vd[3 * LDT] = y[3]; }
+      }
+    }
+  }
+  __syncthreads();
+  // ---------------- phase 2: attn_f32_kernel<32>'s loop over one chunk of 144 keys ----------------
+  const int li = lane & 15, g = lane >> 4;
+  const int q0 = wave * 16, qi = q0 + li;
+  const float kLog2e = 1.44269504088896340736f;
+  float qf[NS];
+  {
+    const float sc = p.scale * kLog2e;
+    const float* qr = Qs + qi * LDK + g * NS;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qf[s] = qr[s] * sc;
+  }
+  const float* bh = p.relbias + ((size_t)h * WS2 + qi) * WS2;
+  const float* bb = p.mask ? p.mask + ((size_t)w * WS2 + qi) * WS2 : nullptr;
+  f32x4 o[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+  f32x4 st[NKT];
+  float cmax = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* kr = Ks + (kt * 16 + li) * LDK + g * NS;
+    f32x4 kq[NS / 4];
+#pragma unroll
+    for (int j = 0; j < NS / 4; ++j) kq[j] = *(const f32x4*)(kr + 4 * j);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kq[s >> 2][s & 3], qf[s], acc, 0, 0, 0);
+    const int key0 = kt * 16 + g * 4;
+    { const f32x4 b = *(const f32x4*)(bh + key0); acc[0] += b[0] * kLog2e; acc[1] += b[1] * kLog2e; acc[2] += b[2] * kLog2e; acc[3] += b[3] * kLog2e; }
+    if (bb) { const f32x4 b = *(const f32x4*)(bb + key0); acc[0] += b[0] * kLog2e; acc[1] += b[1] * kLog2e; acc[2] += b[2] * kLog2e; acc[3] += b[3] * kLog2e; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cmax = fmaxf(cmax, acc[r]);
+    st[kt] = acc;
+  }
+  cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+  cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+  const float mnew = fmaxf(m, cmax);
+  const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+  const float alpha = exp2f(m - msafe);
+  l *= alpha;
+#pragma unroll
+  for (int d = 0; d < ND; ++d) { o[d][0] *= alpha; o[d][1] *= alpha; o[d][2] *= alpha; o[d][3] *= alpha; }
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    f32x4 pr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pr[r] = exp2f(st[kt][r] - msafe); l += pr[r]; }
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+      const f32x4 vv = *(const f32x4*)(Vt + (d * 16 + li) * LDT + kt * 16 + g * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[r], pr[r], o[d], 0, 0, 0);
+    }
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+#pragma unroll
+  for (int d = 0; d < ND; ++d) {
+    const f32x4 y = (f32x4){o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv};
+    const int col = d * 16 + g * 4;
+    half4 hh, lo4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { half_t a, b; split_f16_nt(y[r], a, b); hh[r] = a; lo4[r] = b; }
+    const size_t oo = (size_t)(w * WS2 + qi) * p.ldo + h * DH + col;
+    *(half4*)(p.ohi + oo) = hh;
+    *(half4*)(p.olo + oo) = lo4;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // Fusion-layer bi-attention.
 // ------------------------------------------------------------------------------------------------------------------------------
 // image side: one wave per (image token, head); softmax over the text tokens; also leaves the raw scores for the text side.
@@ -630,6 +788,22 @@ int launch_rowop(const RowOpParams& p, hipStream_t s) {
     if (v4) hipLaunchKernelGGL((rowop_kernel<4, 1>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((rowop_kernel<1, 1>), grid, block, 0, s, p);
   }
+  return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
+}
+
+bool swin_qkv_attn_supported(int C, int nh, int ws, int npass) {
+  return npass == 3 && ws == 12 && nh > 0 && C == nh * 32 && C % 128 == 0;
+}
+
+int launch_swin_qkv_attn(const SwinQkvAttnParams& p, hipStream_t s) {
+  if (p.nW <= 0) return OVM_OK;
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  if (p.C != p.nh * 32 || p.C % 128 || p.KS * 32 < p.C || p.KS % 4 || p.ldx % 8 || p.ldo % 4 || !p.xhi || !p.xlo || !p.wfrag || !p.bias || !p.relbias ||
+      !p.ohi || !p.olo || !al16(p.xhi) || !al16(p.xlo) || !al16(p.wfrag) || !al16(p.bias) || !al16(p.relbias) || (p.mask && !al16(p.mask)))
+    return OVM_ERR_SHAPE;
+  if ((long)p.nW * p.nh > 0x7fffffffL) return OVM_ERR_CAPACITY;
+  const int smem = (2 * 144 * 36 + 32 * 148) * 4;
+  hipLaunchKernelGGL(swin_qkv_attn_kernel, dim3((unsigned)(p.nW * p.nh)), dim3(576), smem, s, p);
   return hipGetLastError() == hipSuccess ? OVM_OK : OVM_ERR_HIP;
 }
 

@@ -56,7 +56,7 @@ struct Tmp {
 };
 }  // namespace
 
-namespace ovm { void set_use_gemm256(int v); void set_gdino_branches(int v); void msdeform_set_vec(int v); void set_gdino_dec_chain(int v); void set_gdino_gemm256(int v); void set_gdino_ffn_split(int v); void gemm256_set_n192(int v); void set_gemm256_ksplit(int v); }
+namespace ovm { void set_use_gemm256(int v); void set_gdino_branches(int v); void msdeform_set_vec(int v); void set_gdino_dec_chain(int v); void set_gdino_gemm256(int v); void set_gdino_swin_fused(int v); void set_gdino_ffn_split(int v); void gemm256_set_n192(int v); void set_gemm256_ksplit(int v); }
 
 extern "C" {
 
@@ -202,6 +202,7 @@ int ovm_tune_set(const char* key, int32_t value) {
     attn_set_pp(value); return OVM_OK;
   }
   if (!strcmp(key, "gdino_ffn_split")) { ovm::set_gdino_ffn_split(value); return OVM_OK; }   // plans built afterwards: 0 = one workgroup per row block runs the whole FFN
+  if (!strcmp(key, "gdino_swin_fused")) { ovm::set_gdino_swin_fused(value); return OVM_OK; }  // plans built afterwards: 0 = qkv GEMM + window attention as two launches
   if (!strcmp(key, "gdino_gemm256")) { ovm::set_gdino_gemm256(value); return OVM_OK; }       // plans built afterwards: 0 = planar rows, 128 x 128 tiles
   if (!strcmp(key, "gdino_dec_chain")) { ovm::set_gdino_dec_chain(value); return OVM_OK; }   // plans built afterwards: 0 = one launch per decoder op
   if (!strcmp(key, "msdeform_vec")) { msdeform_set_vec(value); return OVM_OK; }

@@ -383,3 +383,37 @@ def test_decoder_ffn_chunks_on_separate_workgroups_is_bit_identical(device, size
     if cfg.ffn_dim > 512:
         assert launches[1] == launches[0] + cfg.dec_layers, launches       # one finishing kernel per layer (else this test compares a kernel with itself)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_swin_qkv_projection_inside_the_window_kernel(device):
+    """Round 3: swin_qkv_attn_kernel - one workgroup per (window, head) projects its own q | k | v from the window's split LayerNorm rows
+    (three-pass MFMA over fragment-ordered weights, k-steps of 32 in the 128-tile GEMM's order) into LDS and runs attn_f32_kernel's loop
+    on them. Same products in the same order and the same softmax code (the compiler's contraction choices differ between the two
+    kernels, so not the same bits): the full-size Swin-B detector (all four stages, shifted and unshifted windows, padded windows at
+    532 x 620) must agree with the two-launch form (ovm_tune_set gdino_swin_fused = 0): boxes to 2e-5 (measured 6.6e-06), logits to 1e-4
+    of their largest magnitude (measured 3.2e-04 absolute) after 24 Swin blocks, 6 encoder and 6 decoder layers."""
+    from ovmono3d_amd import lib
+    from ovmono3d_amd.util.synth_gdino_weights import synth_gdino_state_dict
+    L = lib.load()
+    g = torch.Generator().manual_seed(19)
+    sd, hw = synth_gdino_state_dict(3), (532, 620)
+    ids = [101, 2000 + 17, 1012, 2000 + 29, 2000 + 31, 1012, 2000 + 5, 1012, 102]
+    img = torch.randint(0, 256, (3,) + hw, dtype=torch.uint8, generator=g).to(device)
+    outs, launches = [], []
+    try:
+        for fused in (0, 1):
+            assert L.ovm_tune_set(b"gdino_swin_fused", fused) == 0
+            eng = _engine(device, sd, {}, use_graphs=False)
+            logits, boxes = eng.forward(img, ids)
+            outs.append((logits.clone(), boxes.clone()))
+            launches.append(eng.launches())
+            del eng
+    finally:
+        L.ovm_tune_set(b"gdino_swin_fused", 1)
+    assert launches[1] == launches[0] - 24, launches           # 2 + 2 + 18 + 2 Swin-B blocks: one launch less each
+    nid = len(ids)
+    assert torch.isfinite(outs[1][0][:, :nid]).all() and torch.isfinite(outs[1][1]).all()
+    d_box = float((outs[0][1] - outs[1][1]).abs().max()); d_log = float((outs[0][0][:, :nid] - outs[1][0][:, :nid]).abs().max())
+    print(f"swin fused vs two launches: max |d boxes| {d_box:.3e}, max |d logits| {d_log:.3e}")
+    assert_close(outs[1][1], outs[0][1], 2e-5, "pred_boxes (fused Swin window kernel vs two launches)")
+    assert_close(outs[1][0][:, :nid], outs[0][0][:, :nid], 1e-4, "pred_logits (fused Swin window kernel vs two launches)")
