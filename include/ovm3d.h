@@ -354,6 +354,9 @@ int ovm_g_topk(const float* scores, int32_t n, int32_t k, int32_t* out_idx, ovm_
  *   gdino_ffn_split 0|1 (decoder row chains: the FFN's 512-column chunks on separate workgroups + a finishing kernel; bit-identical, faster for the detector alone, not beside the ViT; default 0; read when a plan is built),
  *   gdino_swin_fused 0|1 (Swin blocks: qkv projection inside the window-attention kernel; default 1; read when a plan is built),
  *   gdino_gemm256 0|1 (the detector's wide K <= 256 contractions on the 256 x 256 kernel; default 1; read when a plan is built),
+ *   attn_tail_split 0|1 (attention's leftover queries split over 16 key slices + combine kernel; default 1), attn_prio n (experiment:
+ *   s_setprio inside the two-wave-group attention kernel; default 0), gemm256_ksplit n (experiment: split-K hint of the 256 x 256 kernel for
+ *   proj / fc2; default 0 = off, measured slower), glin_wpe 2|4 (experiment: workgroups per CU the small fp32-A GEMM is compiled for; default 2),
  *   gdino_branches 0|1. Values that select timing-only ablations with wrong results exist in -DOVM_DIAG builds only. */
 int ovm_tune_set(const char* key, int32_t value);
 /* diagnostic hooks: device pointer for a named debug hook ("gemm256_stamps": u64 [8 waves][128] s_memtime stamps of workgroup 0;

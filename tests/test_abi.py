@@ -68,3 +68,18 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("load() must raise when the shared object is absent")
+
+
+def test_every_tune_key_is_documented_and_unknown_keys_are_refused():
+    """ovm_tune_set is part of the C surface: every key csrc/ops.hip accepts is described in include/ovm3d.h, and a key it does not
+    know is an error, not a silent no-op (a typo in OVM_TUNE must not pass for a measurement of the default)."""
+    from ovmono3d_amd import lib
+    ops = open(os.path.join(ROOT, "ovmono3d_amd", "csrc", "ops.hip")).read()
+    hdr = open(os.path.join(ROOT, "include", "ovm3d.h")).read()
+    keys = sorted(set(re.findall(r'!strcmp\(key, "([a-z0-9_]+)"\)', ops)))
+    assert len(keys) >= 25
+    missing = [k for k in keys if not re.search(r"\b" + k + r"\b", hdr)]
+    assert not missing, f"tune keys without a line in include/ovm3d.h: {missing}"
+    L = lib.load()
+    assert L.ovm_tune_set(b"no_such_knob", 1) != 0
+    assert L.ovm_tune_set(None, 1) != 0
