@@ -10,9 +10,10 @@
 int main(int argc, char** argv) {
   std::vector<std::vector<unsigned char>> seeds;
   for (int i = 1; i < argc; ++i) { FILE* f = fopen(argv[i], "rb"); std::vector<unsigned char> b; int c; while ((c = fgetc(f)) != EOF) b.push_back((unsigned char)c); fclose(f); seeds.push_back(b); }
-  std::mt19937 g(1);
+  const long N = getenv("FUZZ_N") ? atol(getenv("FUZZ_N")) : 20000;      // FUZZ_N / FUZZ_SEED: longer runs with other streams
+  std::mt19937 g(getenv("FUZZ_SEED") ? (unsigned)atol(getenv("FUZZ_SEED")) : 1u);
   long ok = 0, bad = 0;
-  for (int it = 0; it < 20000; ++it) {
+  for (long it = 0; it < N; ++it) {
     std::vector<unsigned char> d = seeds[it % seeds.size()];
     if (d.size() > 20000) d.resize(20000);
     int kind = g() % 4;
